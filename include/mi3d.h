@@ -1,0 +1,137 @@
+/*
+ * mi3d.h - C ABI of libmi3d.so, the MI355X (gfx950) implementation of Make-It-3D's coarse-stage
+ * SDS hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ * parameter name ends in `_host`.  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Every entry point enqueues work on `stream` and returns the hipError_t of the launch
+ * as int (0 = hipSuccess); nothing here allocates, frees or synchronises.
+ *
+ * Part 1 replaces, one for one, the 13 functions of the reference's `_raymarching` backend
+ * (/root/reference/raymarching/src/raymarching.h:7-22, bound in bindings.cpp:5-23): same argument
+ * order and meaning, `at::Tensor` -> raw pointer, plus the trailing stream.  Caller allocates all
+ * outputs (as raymarching/raymarching.py does).
+ *
+ * Part 2 replaces the tiny-cuda-nn `Encoding` (HashGrid) forward/backward the reference calls at
+ * /root/reference/nerf/network_tcnn.py:54-65,107.
+ *
+ * Part 3 evaluates / back-propagates the encoder for the whole 13-point stencil the reference visits with
+ * 13 separate encoder passes per sample (network_tcnn.py:115-128, nerf/renderer.py:521-524).
+ */
+#ifndef MI3D_H
+#define MI3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI3D_MAX_LEVELS 16
+#define MI3D_MAX_POINTS 16
+
+/* library / device sanity: returns the ABI version; *n_devices_host gets hipGetDeviceCount (or -1) */
+int mi3d_abi_version(void);
+const char *mi3d_last_error_string(int err);
+
+/* ------------------------------------------------------------------ Part 1: raymarching backend */
+
+/* raymarching.h:7  near_far_from_aabb -- rays_o,rays_d [N,3]; aabb [6]; nears,fars [N] */
+int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                            float min_near, float *nears, float *fars, void *stream);
+/* raymarching.h:8  sph_from_ray -- coords [N,2] */
+int mi3d_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                      void *stream);
+/* raymarching.h:9  morton3D -- coords int32 [N,3] -> indices int32 [N] */
+int mi3d_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream);
+/* raymarching.h:10 morton3D_invert */
+int mi3d_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream);
+/* raymarching.h:11 packbits -- grid float [N*8] -> bitfield uint8 [N] (bit i = grid[8n+i] > thresh) */
+int mi3d_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream);
+
+/* raymarching.h:13 march_rays_train -- xyzs,dirs [M,3]; deltas [M,2]; rays int32 [N,3] = (ray id, offset,
+ * count); counter int32 [2] (+= samples, += rays).  Rows are written only for rays whose slab fits in M.
+ * Slabs are handed out by one atomic per workgroup after an in-workgroup scan (rays[] rows are in ray
+ * order: rays[n] describes ray n). */
+int mi3d_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                          int32_t *rays, int32_t *counter, const float *noises, void *stream);
+/* Not in the reference: zero rows [counter[0], counter[0]+pad) of xyzs/dirs/deltas (pad < align), the rows
+ * raymarching.py:237-241 exposes past the last sample; lets the caller skip the 537 MB zero fill of
+ * raymarching.py:217-219. */
+int mi3d_march_zero_tail(const int32_t *counter, uint32_t align, uint32_t M, float *xyzs, float *dirs,
+                         float *deltas, void *stream);
+
+/* raymarching.h:14-15 composite_rays_train_{forward,backward} */
+int mi3d_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                      const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                      float *weights_sum, float *depth, float *image, void *stream);
+int mi3d_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                       const float *sigmas, const float *rgbs, const float *deltas,
+                                       const int32_t *rays, const float *weights_sum, const float *image,
+                                       uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                       float *grad_rgbs, void *stream);
+/* raymarching.h:16-17 composite_sdf_rays_train_{forward,backward} (alpha = sigma) */
+int mi3d_composite_sdf_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                          const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                          float *weights_sum, float *depth, float *image, void *stream);
+int mi3d_composite_sdf_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                           const float *sigmas, const float *rgbs, const float *deltas,
+                                           const int32_t *rays, const float *weights_sum, const float *image,
+                                           uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                           float *grad_rgbs, void *stream);
+
+/* raymarching.h:20 march_rays (inference) */
+int mi3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                    const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                    uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
+                    float *xyzs, float *dirs, float *deltas, const float *noises, void *stream);
+/* raymarching.h:21 composite_rays (inference, in place) */
+int mi3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                        const float *sigmas, const float *rgbs, const float *normals, const float *deltas,
+                        float *weights_sum, float *depth, float *image, float *normal, void *stream);
+/* raymarching.h:22 composite_sdf_rays */
+int mi3d_composite_sdf_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                            float *rays_t, const float *sigmas, const float *rgbs, const float *deltas,
+                            float *weights_sum, float *depth, float *image, void *stream);
+
+/* ------------------------------------------------------------------ Part 2: hash-grid encoding */
+
+/* Level table of a tcnn HashGrid (host side; no device work).  offsets_host has n_levels+1 entries in
+ * units of grid entries (x n_features=2 floats).  Returns the total number of entries. */
+uint32_t mi3d_hashgrid_levels(uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
+                              uint32_t log2_hashmap_size, uint32_t *offsets_host, uint32_t *resolutions_host,
+                              float *scales_host);
+
+/* tcnn.Encoding.forward: x [n,3] in [0,1]; params fp32 [entries*2]; out [n, n_levels*2] (feature = level*2+f) */
+int mi3d_hashgrid_forward(const float *x, uint32_t n, const float *params, uint32_t n_levels,
+                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                          float *out, void *stream);
+/* tcnn.Encoding.backward wrt params: grad_params [entries*2] is ACCUMULATED into (caller zeroes it) */
+int mi3d_hashgrid_backward(const float *x, uint32_t n, const float *dout, uint32_t n_levels,
+                           uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                           float *grad_params, void *stream);
+
+/* ------------------------------------------------------------------ Part 3: stencil-aware grid ops */
+
+/* The reference evaluates the field at 13 points per sample: x, x +- eps e_i (finite_difference_normal,
+ * network_tcnn.py:115-128) and the same six offsets around x2 = x + 0.01 randn (loss_smooth,
+ * nerf/renderer.py:521-524), each as a separate encoder pass.  These two entry points take the whole stencil:
+ * point p of sample i is clamp(base + offsets[p], -bound, bound) with base = x[i] for p < P0 and x2[i] for
+ * P0 <= p < P (x2 may be NULL when P0 == P), mapped to [0,1] as (pt + bound) / (2 bound) (network_tcnn.py:106).
+ * Row (i*P + p) of `out` / `dout` holds the n_levels*2 features of that point.
+ * `count` (device int32, may be NULL) caps n at min(n, *count) without a host round trip.
+ * `step` (scatter only): the marching step dt_min in world units (0 = unknown); it only selects which levels
+ * use run-merging vs lane-quad atomics, never the result. */
+int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
+                            const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *params,
+                            uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
+                            uint32_t log2_hashmap_size, float *out, void *stream);
+int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
+                             const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,
+                             uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
+                             uint32_t log2_hashmap_size, float step, float *grad_params, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI3D_H */

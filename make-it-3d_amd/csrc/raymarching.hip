@@ -1,0 +1,540 @@
+// Occupancy-grid ray marching and volume compositing for MI355X (gfx950, wave64).
+//
+// Implements Part 1 of include/mi3d.h - the 13 entry points the reference binds in
+// /root/reference/raymarching/src/bindings.cpp:5-23 - as native HIP:
+//
+//  * march_rays_train : one wave = 64 rays, one workgroup = one wave (N/64 workgroups so a 128x128
+//    view already fills the 256 CUs).  Count pass -> wave64 inclusive scan of the per-ray sample
+//    counts -> ONE atomic per wave reserves the slab for all 64 rays (the reference issues two
+//    global atomics per ray, raymarching.cu:405-406) -> write pass.  rays[] rows are in ray order.
+//  * composite_rays_train fwd/bwd : one wave per RAY.  Lanes load 64 consecutive samples of the ray
+//    (coalesced; the reference reads with a stride of one ray length between lanes), transmittance
+//    is a wave64 multiplicative prefix scan, early termination is a ballot + first-set-lane, sums are
+//    wave reductions.  Same quadrature, same break rule (accumulate the crossing sample, then stop:
+//    raymarching.cu:554-557), results agree with the sequential loop to fp32 rounding.
+//  * utilities (near/far, sph, morton, packbits) and the inference march/composite: one thread per
+//    element, vectorised loads where the layout allows.
+//
+// Compiled with -ffp-contract=off: fused multiply-adds are explicit (mi3d_common.h).
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+
+#include "../../include/mi3d.h"
+#include "mi3d_common.h"
+
+using namespace mi3d;
+
+namespace {
+
+constexpr int kWave = 64;
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return (int)hipGetLastError(); }
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- wave64 primitives
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {  // inclusive
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_up(v, off, kWave);
+        if (lane >= off) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {  // inclusive
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v, int lane) {  // inclusive
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// ---------------------------------------------------------------- utilities
+
+__global__ void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                           const float *__restrict__ aabb, uint32_t N, float min_near, float *__restrict__ nears,
+                           float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
+
+    // slab test, axis by axis; a miss on any axis marks the ray with FLT_MAX on both ends
+    float lo = (aabb[0] - ox) * rdx, hi = (aabb[3] - ox) * rdx;
+    if (lo > hi) { const float s = lo; lo = hi; hi = s; }
+    float lo2 = (aabb[1] - oy) * rdy, hi2 = (aabb[4] - oy) * rdy;
+    if (lo2 > hi2) { const float s = lo2; lo2 = hi2; hi2 = s; }
+    bool miss = (lo > hi2) || (lo2 > hi);
+    if (!miss) {
+        if (lo2 > lo) lo = lo2;
+        if (hi2 < hi) hi = hi2;
+        float lo3 = (aabb[2] - oz) * rdz, hi3 = (aabb[5] - oz) * rdz;
+        if (lo3 > hi3) { const float s = lo3; lo3 = hi3; hi3 = s; }
+        miss = (lo > hi3) || (lo3 > hi);
+        if (!miss) {
+            if (lo3 > lo) lo = lo3;
+            if (hi3 < hi) hi = hi3;
+            if (lo < min_near) lo = min_near;
+        }
+    }
+    nears[n] = miss ? FLT_MAX : lo;
+    fars[n] = miss ? FLT_MAX : hi;
+}
+
+__global__ void k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
+                               uint32_t N, float *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    // far intersection of o + t d with the sphere |p| = radius
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;
+    const float Cq = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * Cq)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    coords[n * 2] = 2 * atan2f(sqrtf(x * x + z * z), y) * kRPi - 1;
+    coords[n * 2 + 1] = atan2f(z, x) * kRPi;
+}
+
+__global__ void k_morton3d(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3d((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+
+__global__ void k_morton3d_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t code = indices[n];  // signed shifts, as the reference shifts an `int`
+    coords[n * 3] = (int32_t)compact_bits((uint32_t)(code >> 0));
+    coords[n * 3 + 1] = (int32_t)compact_bits((uint32_t)(code >> 1));
+    coords[n * 3 + 2] = (int32_t)compact_bits((uint32_t)(code >> 2));
+}
+
+// one thread per output byte; the 8 floats are two aligned 16-byte loads
+__global__ void k_packbits(const float4 *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bits) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = grid[(size_t)n * 2], b = grid[(size_t)n * 2 + 1];
+    uint32_t v = 0;
+    v |= (a.x > thresh) ? 1u : 0u;   v |= (a.y > thresh) ? 2u : 0u;
+    v |= (a.z > thresh) ? 4u : 0u;   v |= (a.w > thresh) ? 8u : 0u;
+    v |= (b.x > thresh) ? 16u : 0u;  v |= (b.y > thresh) ? 32u : 0u;
+    v |= (b.z > thresh) ? 64u : 0u;  v |= (b.w > thresh) ? 128u : 0u;
+    bits[n] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------- training march
+
+__global__ __launch_bounds__(kWave) void k_march_train(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ bits,
+    float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+    const float *__restrict__ nears, const float *__restrict__ fars, float *__restrict__ xyzs,
+    float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *counter,
+    const float *__restrict__ noises) {
+    const int lane = lane_id();
+    const uint32_t n = blockIdx.x * kWave + lane;
+    const bool live = n < N;
+
+    MarchGrid g;
+    march_grid_init(g, bits, bound, dt_gamma, max_steps, C, H);
+    MarchRay r;
+    float far = 0.f, t0 = 0.f;
+    if (live) {
+        march_ray_init(r, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+        far = fars[n];
+        t0 = march_t0(nears[n], noises[n], g);
+    }
+
+    // pass 1: how many occupied steps does this ray take?
+    uint32_t count = 0;
+    if (live) {
+        float t = t0, x, y, z, dt;
+        while (t < far && count < max_steps)
+            if (march_step(r, g, t, x, y, z, dt)) ++count;
+    }
+
+    // slab reservation: wave scan + one atomic per wave (counter[0] += samples, counter[1] += rays)
+    const uint32_t incl = wave_scan_add_u32(count, lane);
+    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+    uint32_t base = 0;
+    if (lane == 0) {
+        base = (uint32_t)atomicAdd(counter, (int)wave_total);
+        const uint32_t rays_here = (N - blockIdx.x * kWave) < (uint32_t)kWave ? (N - blockIdx.x * kWave) : (uint32_t)kWave;
+        atomicAdd(counter + 1, (int)rays_here);
+    }
+    base = __shfl(base, 0, kWave);
+    const uint32_t offset = base + incl - count;
+    if (!live) return;
+
+    rays[(size_t)n * 3] = (int32_t)n;
+    rays[(size_t)n * 3 + 1] = (int32_t)offset;
+    rays[(size_t)n * 3 + 2] = (int32_t)count;
+    if (count == 0 || offset + count > M) return;  // overflowing rays are dropped, not an error
+
+    // pass 2: replay the same walk and emit the samples
+    float *px = xyzs + (size_t)offset * 3, *pd = dirs + (size_t)offset * 3, *pl = deltas + (size_t)offset * 2;
+    float t = t0, last_t = t0, x, y, z, dt;
+    uint32_t step = 0;
+    while (t < far && step < count) {
+        if (march_step(r, g, t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            ++step;
+        }
+    }
+}
+
+// zero the `align` padding rows the Python wrapper exposes after the last sample
+__global__ void k_march_zero_tail(const int32_t *__restrict__ counter, uint32_t align, uint32_t M,
+                                  float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t m = (uint32_t)counter[0];
+    if (m >= M) return;
+    uint32_t pad = align - m % align;
+    if (m + pad > M) pad = M - m;
+    for (uint32_t i = threadIdx.x; i < pad * 3; i += blockDim.x) {
+        xyzs[(size_t)m * 3 + i] = 0.f;
+        dirs[(size_t)m * 3 + i] = 0.f;
+    }
+    for (uint32_t i = threadIdx.x; i < pad * 2; i += blockDim.x) deltas[(size_t)m * 2 + i] = 0.f;
+}
+
+// ---------------------------------------------------------------- training composite (wave per ray)
+
+struct CompositeChunk {
+    float alpha, w, T_incl, t_incl;
+    bool active;      // this lane's sample contributes
+    bool terminated;  // the ray stopped inside this chunk (wave-uniform)
+};
+
+// Shared by forward and backward: loads 64 consecutive samples, returns weights/transmittance.
+// T_run / t_run are wave-uniform carries (transmittance and depth parameter before this chunk).
+template <bool SDF>
+__device__ __forceinline__ CompositeChunk composite_chunk(const float *__restrict__ sigmas,
+                                                          const float *__restrict__ deltas, uint32_t i, bool valid,
+                                                          int lane, float T_thresh, float &T_run, float &t_run) {
+    CompositeChunk c;
+    float sigma = 0.f, d0 = 0.f, d1 = 0.f;
+    if (valid) {
+        sigma = sigmas[i];
+        const float2 dl = reinterpret_cast<const float2 *>(deltas)[i];
+        d0 = dl.x; d1 = dl.y;
+    }
+    c.alpha = valid ? (SDF ? sigma : 1.0f - __expf(-sigma * d0)) : 0.f;
+    const float P = wave_scan_mul(1.0f - c.alpha, lane);  // inclusive product of (1 - alpha)
+    float P_excl = __shfl_up(P, 1, kWave);
+    if (lane == 0) P_excl = 1.0f;
+    c.T_incl = T_run * P;
+    const float T_excl = T_run * P_excl;
+    const float S = wave_scan_add(d1, lane);
+    c.t_incl = t_run + S;
+
+    // the reference accumulates the sample that drops T below the threshold, then stops
+    const unsigned long long stop = __ballot(valid && (c.T_incl < T_thresh));
+    c.terminated = stop != 0ull;
+    const int last = c.terminated ? (int)__ffsll((long long)stop) - 1 : kWave - 1;
+    c.active = valid && lane <= last;
+    c.w = c.active ? c.alpha * T_excl : 0.f;
+
+    T_run = __shfl(c.T_incl, last, kWave);  // transmittance after the last processed sample of the chunk
+    t_run = t_run + __shfl(S, kWave - 1, kWave);
+    return c;
+}
+
+template <bool SDF>
+__global__ __launch_bounds__(256) void k_composite_train_fwd(
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+    const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float *__restrict__ weights_sum,
+    float *__restrict__ depth, float *__restrict__ image) {
+    const int lane = lane_id();
+    const uint32_t row = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (row >= N) return;
+    const uint32_t index = (uint32_t)rays[(size_t)row * 3], offset = (uint32_t)rays[(size_t)row * 3 + 1],
+                   num_steps = (uint32_t)rays[(size_t)row * 3 + 2];
+
+    float r = 0.f, g = 0.f, b = 0.f, d = 0.f, ws = 0.f, T_run = 1.0f, t_run = 0.f;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        for (uint32_t base = 0; base < num_steps; base += kWave) {
+            const uint32_t i = offset + base + lane;
+            const bool valid = base + lane < num_steps;
+            const CompositeChunk c = composite_chunk<SDF>(sigmas, deltas, i, valid, lane, T_thresh, T_run, t_run);
+            if (c.active) {
+                const float *col = rgbs + (size_t)i * 3;
+                r += c.w * col[0]; g += c.w * col[1]; b += c.w * col[2];
+                d += c.w * c.t_incl;
+                ws += c.w;
+            }
+            if (c.terminated) break;
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); d = wave_sum(d); ws = wave_sum(ws);
+        if (SDF) ws = 1.0f - T_run;
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    }
+}
+
+template <bool SDF>
+__global__ __launch_bounds__(256) void k_composite_train_bwd(
+    const float *__restrict__ grad_ws, const float *__restrict__ grad_image, const float *__restrict__ sigmas,
+    const float *__restrict__ rgbs, const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+    const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+    float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs) {
+    const int lane = lane_id();
+    const uint32_t row = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (row >= N) return;
+    const uint32_t index = (uint32_t)rays[(size_t)row * 3], offset = (uint32_t)rays[(size_t)row * 3 + 1],
+                   num_steps = (uint32_t)rays[(size_t)row * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+
+    const float gws = grad_ws[index], ws_final = weights_sum[index];
+    const float gi0 = grad_image[(size_t)index * 3], gi1 = grad_image[(size_t)index * 3 + 1],
+                gi2 = grad_image[(size_t)index * 3 + 2];
+    const float rf = image[(size_t)index * 3], gf = image[(size_t)index * 3 + 1], bf = image[(size_t)index * 3 + 2];
+    const float ws_term = gws * (1.0f - ws_final);
+
+    float T_run = 1.0f, t_run = 0.f, r_run = 0.f, g_run = 0.f, b_run = 0.f;  // colour accumulated before chunk
+    for (uint32_t base = 0; base < num_steps; base += kWave) {
+        const uint32_t i = offset + base + lane;
+        const bool valid = base + lane < num_steps;
+        const CompositeChunk c = composite_chunk<SDF>(sigmas, deltas, i, valid, lane, T_thresh, T_run, t_run);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, d0 = 0.f;
+        if (valid) {
+            const float *col = rgbs + (size_t)i * 3;
+            c0 = col[0]; c1 = col[1]; c2 = col[2];
+            d0 = deltas[(size_t)i * 2];
+        }
+        // colour accumulated up to and including this sample
+        const float sr = wave_scan_add(c.w * c0, lane), sg = wave_scan_add(c.w * c1, lane),
+                    sb = wave_scan_add(c.w * c2, lane);
+        if (c.active) {
+            const float r = r_run + sr, g = g_run + sg, b = b_run + sb;
+            float *gc = grad_rgbs + (size_t)i * 3;
+            gc[0] = gi0 * c.w; gc[1] = gi1 * c.w; gc[2] = gi2 * c.w;
+            grad_sigmas[i] = d0 * (gi0 * (c.T_incl * c0 - (rf - r)) + gi1 * (c.T_incl * c1 - (gf - g)) +
+                                   gi2 * (c.T_incl * c2 - (bf - b)) + ws_term);
+        }
+        if (c.terminated) break;
+        r_run += __shfl(sr, kWave - 1, kWave);
+        g_run += __shfl(sg, kWave - 1, kWave);
+        b_run += __shfl(sb, kWave - 1, kWave);
+    }
+}
+
+// ---------------------------------------------------------------- inference (one thread per alive ray)
+
+__global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                              const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                              const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                              uint32_t C, uint32_t H, const uint8_t *__restrict__ bits,
+                              const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                              float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    MarchGrid g;
+    march_grid_init(g, bits, bound, dt_gamma, max_steps, C, H);
+    MarchRay r;
+    march_ray_init(r, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3);
+    const float far = fars[index];
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3,
+          *pl = deltas + (size_t)n * n_step * 2;
+    float t = march_t0(rays_t[index], noises[n], g);
+    float last_t = t, x, y, z, dt;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        if (march_step(r, g, t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            ++step;
+        }
+    }
+}
+
+template <bool SDF>
+__global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                                  float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                  const float *__restrict__ rgbs, const float *__restrict__ normals,
+                                  const float *__restrict__ deltas, float *__restrict__ weights_sum,
+                                  float *__restrict__ depth, float *__restrict__ image, float *__restrict__ normal) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3,
+                *dl = deltas + (size_t)n * n_step * 2;
+    const float *nm = SDF ? nullptr : normals + (size_t)n * n_step * 3;
+
+    float t = rays_t[index], d = depth[index], ws = weights_sum[index];
+    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (!SDF) { nx = normal[(size_t)index * 3]; ny = normal[(size_t)index * 3 + 1]; nz = normal[(size_t)index * 3 + 2]; }
+
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0.f) break;  // rows past the ray's end are zero: the ray is finished
+        const float alpha = SDF ? s[0] : 1.0f - __expf(-s[0] * dl[0]);
+        const float T = 1.0f - ws;  // transmittance carried across calls through weights_sum
+        const float w = alpha * T;
+        ws += w;
+        t += dl[1];
+        d += w * t;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        if (!SDF) { nx += w * nm[0]; ny += w * nm[1]; nz += w * nm[2]; nm += 3; }
+        if (T < T_thresh) break;
+        ++s; c += 3; dl += 2;
+        ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    if (!SDF) { normal[(size_t)index * 3] = nx; normal[(size_t)index * 3 + 1] = ny; normal[(size_t)index * 3 + 2] = nz; }
+}
+
+}  // namespace
+
+// ================================================================ C ABI
+
+extern "C" {
+
+int mi3d_abi_version(void) { return 1; }
+const char *mi3d_last_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                            float *nears, float *fars, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_near_far, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, N,
+                       min_near, nears, fars);
+    return launch_status();
+}
+
+int mi3d_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                      void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, radius, N,
+                       coords);
+    return launch_status();
+}
+
+int mi3d_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_morton3d, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), coords, N, indices);
+    return launch_status();
+}
+
+int mi3d_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_morton3d_invert, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), indices, N, coords);
+    return launch_status();
+}
+
+int mi3d_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_packbits, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(grid), N, density_thresh, bitfield);
+    return launch_status();
+}
+
+int mi3d_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                          const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                          const float *noises, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_march_train, dim3(cdiv(N, kWave)), dim3(kWave), 0, as_stream(stream), rays_o, rays_d, grid,
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises);
+    return launch_status();
+}
+
+int mi3d_march_zero_tail(const int32_t *counter, uint32_t align, uint32_t M, float *xyzs, float *dirs, float *deltas,
+                         void *stream) {
+    if (align == 0 || M == 0) return 0;
+    hipLaunchKernelGGL(k_march_zero_tail, dim3(1), dim3(256), 0, as_stream(stream), counter, align, M, xyzs, dirs,
+                       deltas);
+    return launch_status();
+}
+
+#define MI3D_COMPOSITE_FWD(NAME, SDF)                                                                               \
+    int NAME(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,          \
+             uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image, void *stream) {            \
+        if (N == 0) return 0;                                                                                       \
+        hipLaunchKernelGGL(k_composite_train_fwd<SDF>, dim3(cdiv(N, 4)), dim3(256), 0, as_stream(stream), sigmas,   \
+                           rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);                          \
+        return launch_status();                                                                                     \
+    }
+MI3D_COMPOSITE_FWD(mi3d_composite_rays_train_forward, false)
+MI3D_COMPOSITE_FWD(mi3d_composite_sdf_rays_train_forward, true)
+
+#define MI3D_COMPOSITE_BWD(NAME, SDF)                                                                               \
+    int NAME(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,        \
+             const float *deltas, const int32_t *rays, const float *weights_sum, const float *image, uint32_t M,    \
+             uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs, void *stream) {                      \
+        if (N == 0) return 0;                                                                                       \
+        hipLaunchKernelGGL(k_composite_train_bwd<SDF>, dim3(cdiv(N, 4)), dim3(256), 0, as_stream(stream),           \
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,      \
+                           T_thresh, grad_sigmas, grad_rgbs);                                                       \
+        return launch_status();                                                                                     \
+    }
+MI3D_COMPOSITE_BWD(mi3d_composite_rays_train_backward, false)
+MI3D_COMPOSITE_BWD(mi3d_composite_sdf_rays_train_backward, true)
+
+int mi3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                    const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                    uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
+                    float *dirs, float *deltas, const float *noises, void *stream) {
+    (void)nears;  // read but unused by the reference kernel as well (raymarching.cu:943)
+    if (n_alive == 0) return 0;
+    hipLaunchKernelGGL(k_march_infer, dim3(cdiv(n_alive, 128)), dim3(128), 0, as_stream(stream), n_alive, n_step,
+                       rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
+                       deltas, noises);
+    return launch_status();
+}
+
+int mi3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                        const float *sigmas, const float *rgbs, const float *normals, const float *deltas,
+                        float *weights_sum, float *depth, float *image, float *normal, void *stream) {
+    if (n_alive == 0) return 0;
+    hipLaunchKernelGGL(k_composite_infer<false>, dim3(cdiv(n_alive, 128)), dim3(128), 0, as_stream(stream), n_alive,
+                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth, image,
+                       normal);
+    return launch_status();
+}
+
+int mi3d_composite_sdf_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                            const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
+                            float *depth, float *image, void *stream) {
+    if (n_alive == 0) return 0;
+    hipLaunchKernelGGL(k_composite_infer<true>, dim3(cdiv(n_alive, 128)), dim3(128), 0, as_stream(stream), n_alive,
+                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, nullptr, deltas, weights_sum, depth, image,
+                       nullptr);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+"""Stencil-aware hash-grid encode (autograd): all P evaluation points of every sample in one launch, backward through
+the request-minimising scatter of csrc/hashgrid.hip (Part 3 of include/mi3d.h)."""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+EPS = 1e-2  # finite_difference_normal epsilon (network_tcnn.py:115)
+# the six offsets of network_tcnn.py:117-122, in that order: +x, -x, +y, -y, +z, -z
+STENCIL6 = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32) * np.float32(EPS)
+
+
+def stencil_offsets(center=True, second=False):
+    """[P,3] offsets: optional centre point, the 6-point stencil around x, optionally the same 6 around x2."""
+    parts = ([np.zeros((1, 3), np.float32)] if center else []) + [STENCIL6] + ([STENCIL6] if second else [])
+    offs = np.concatenate(parts, 0)
+    P0 = (1 if center else 0) + 6
+    return offs, (P0 if second else offs.shape[0])
+
+
+def _offs_arg(offsets):
+    offsets = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1, 3)
+    return offsets, offsets.ctypes.data_as(C.c_void_p)
+
+
+class _EncodePoints(Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, params, x, x2, offsets, P0, bound, cfg, step, count):
+        x = L.dev_f32(x.contiguous().view(-1, 3), "x", 3)
+        if x2 is not None:
+            x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
+        params = L.dev_f32(params, "params")
+        offs, offs_p = _offs_arg(offsets)
+        P, n = offs.shape[0], x.shape[0]
+        out = torch.empty(n * P, cfg["n_levels"] * 2, dtype=torch.float32, device=x.device)
+        if count is not None:  # rows past *count are not written by the kernel
+            out.zero_()
+        L.call("mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
+               L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"],
+               cfg["log2_hashmap_size"], L.ptr(out), L.stream())
+        ctx.save_for_backward(x, x2 if x2 is not None else x, count if count is not None else x)
+        ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, count is not None, params.numel())
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        x, x2, count = ctx.saved_tensors
+        offs, P0, bound, cfg, step, has_x2, has_count, n_params = ctx.meta
+        dout = L.dev_f32(dout.float().contiguous(), "dout")
+        grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
+        _, offs_p = _offs_arg(offs)
+        L.call("mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
+               L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
+               cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad),
+               L.stream())
+        return grad, None, None, None, None, None, None, None, None
+
+
+def encode_points(params, x, offsets, cfg, bound=1.0, x2=None, P0=None, step=0.0, count=None):
+    """features [n*P, 2L] (row = sample*P + point) of clamp(base + offsets[p]) for every sample; differentiable
+    w.r.t. `params`."""
+    P = np.asarray(offsets).reshape(-1, 3).shape[0]
+    if P0 is None:
+        P0 = P
+    return _EncodePoints.apply(params, x, x2, offsets, P0, bound, cfg, step, count)

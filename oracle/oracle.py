@@ -1,0 +1,317 @@
+"""ORACLE (test infrastructure, NOT product code).
+
+numpy front-end of `oracle/liboracle.so`, the plain-C restatement of the
+reference's hot path (see the headers of raymarching_ref.c / hashgrid_ref.c /
+field_ref.c for the file:line each function follows).  The wrappers here restate
+the *Python* side of the reference operators - output allocation, zero fill and
+the `align` padding rule of /root/reference/raymarching/raymarching.py:207-245,
+269-300, 397-414 - so a test can call `oracle.march_rays_train(...)` exactly
+like `raymarching.march_rays_train(...)`.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Nothing under make-it-3d_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("raymarching_ref.c", "hashgrid_ref.c", "field_ref.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ref_hashgrid_levels.restype = C.c_uint32
+        _LIB.ref_round_half.restype = C.c_float
+        _LIB.ref_round_half.argtypes = [C.c_float]
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+u32, f32, f64 = C.c_uint32, C.c_float, C.c_double
+
+# ----------------------------------------------------------------------------- raymarching ops
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+    rays_o, rays_d, aabb = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3), _f(aabb)
+    N = rays_o.shape[0]
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    lib().ref_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), u32(N), f32(min_near), _p(nears), _p(fars))
+    return nears, fars
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    rays_o, rays_d = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3)
+    N = rays_o.shape[0]
+    coords = np.empty((N, 2), np.float32)
+    lib().ref_sph_from_ray(_p(rays_o), _p(rays_d), f32(radius), u32(N), _p(coords))
+    return coords
+
+
+def morton3D(coords):
+    coords = np.ascontiguousarray(coords, dtype=np.int32)
+    N = coords.shape[0]
+    out = np.empty(N, np.int32)
+    lib().ref_morton3D(_p(coords), u32(N), _p(out))
+    return out
+
+
+def morton3D_invert(indices):
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    N = indices.shape[0]
+    out = np.empty((N, 3), np.int32)
+    lib().ref_morton3D_invert(_p(indices), u32(N), _p(out))
+    return out
+
+
+def packbits(grid, thresh):
+    grid = _f(grid)
+    N = grid.size // 8
+    out = np.empty(N, np.uint8)
+    lib().ref_packbits(_p(grid), u32(N), f32(thresh), _p(out))
+    return out
+
+
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C_, H, nears, fars, noises=None, align=-1,
+                     dt_gamma=0.0, max_steps=1024, M=None, return_counter=False):
+    """raymarching.py:173-247 with force_all_rays=True; `noises` replaces torch.rand (None = perturb off)."""
+    rays_o, rays_d = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3)
+    bits = np.ascontiguousarray(density_bitfield, dtype=np.uint8)
+    nears, fars = _f(nears), _f(fars)
+    N = rays_o.shape[0]
+    if M is None:
+        M = N * max_steps
+    noises = np.zeros(N, np.float32) if noises is None else _f(noises)
+    xyzs = np.zeros((M, 3), np.float32)
+    dirs = np.zeros((M, 3), np.float32)
+    deltas = np.zeros((M, 2), np.float32)
+    rays = np.empty((N, 3), np.int32)
+    counter = np.zeros(2, np.int32)
+    lib().ref_march_rays_train(_p(rays_o), _p(rays_d), _p(bits), f32(bound), f32(dt_gamma), u32(max_steps), u32(N),
+                               u32(C_), u32(H), u32(M), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas),
+                               _p(rays), _p(counter), _p(noises))
+    m = int(counter[0])
+    if align > 0:
+        m += align - m % align  # raymarching.py:237-238 (adds a full `align` when m % align == 0)
+    m = min(m, M)
+    out = (xyzs[:m], dirs[:m], deltas[:m], rays)
+    return out + (counter,) if return_counter else out
+
+
+def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, sdf=False):
+    sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
+    rays = np.ascontiguousarray(rays, dtype=np.int32)
+    M, N = sigmas.shape[0], rays.shape[0]
+    ws, depth, image = np.empty(N, np.float32), np.empty(N, np.float32), np.empty((N, 3), np.float32)
+    fn = lib().ref_composite_sdf_rays_train_forward if sdf else lib().ref_composite_rays_train_forward
+    fn(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), u32(M), u32(N), f32(T_thresh), _p(ws), _p(depth), _p(image))
+    return ws, depth, image
+
+
+def composite_rays_train_backward(grad_ws, grad_image, sigmas, rgbs, deltas, rays, ws, image, T_thresh=1e-4,
+                                  sdf=False):
+    grad_ws, grad_image, sigmas, rgbs, deltas, ws, image = map(_f, (grad_ws, grad_image, sigmas, rgbs, deltas, ws,
+                                                                   image))
+    rays = np.ascontiguousarray(rays, dtype=np.int32)
+    M, N = sigmas.shape[0], rays.shape[0]
+    gs, gc = np.zeros_like(sigmas), np.zeros_like(rgbs)  # raymarching.py:295-296
+    fn = lib().ref_composite_sdf_rays_train_backward if sdf else lib().ref_composite_rays_train_backward
+    fn(_p(grad_ws), _p(grad_image), _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _p(ws), _p(image), u32(M), u32(N),
+       f32(T_thresh), _p(gs), _p(gc))
+    return gs, gc
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C_, H, nears, fars,
+               align=-1, noises=None, dt_gamma=0.0, max_steps=1024):
+    """raymarching.py:365-414."""
+    rays_o, rays_d = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3)
+    rays_alive = np.ascontiguousarray(rays_alive, dtype=np.int32)
+    rays_t, nears, fars = _f(rays_t), _f(nears), _f(fars)
+    bits = np.ascontiguousarray(density_bitfield, dtype=np.uint8)
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    noises = np.zeros(n_alive, np.float32) if noises is None else _f(noises)
+    lib().ref_march_rays(u32(n_alive), u32(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d), f32(bound),
+                         f32(dt_gamma), u32(max_steps), u32(C_), u32(H), _p(bits), _p(nears), _p(fars), _p(xyzs),
+                         _p(dirs), _p(deltas), _p(noises))
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth, image,
+                   normal, T_thresh=1e-2):
+    """In-place like raymarching.py:419-447: mutates rays_alive, rays_t, weights_sum, depth, image, normal
+    (all must be C-contiguous numpy arrays of the right dtype)."""
+    sigmas, rgbs, normals, deltas = _f(sigmas), _f(rgbs), _f(normals), _f(deltas)
+    for a, dt in ((rays_alive, np.int32), (rays_t, np.float32), (weights_sum, np.float32), (depth, np.float32),
+                  (image, np.float32), (normal, np.float32)):
+        assert a.dtype == dt and a.flags.c_contiguous
+    lib().ref_composite_rays(u32(n_alive), u32(n_step), f32(T_thresh), _p(rays_alive), _p(rays_t), _p(sigmas),
+                             _p(rgbs), _p(normals), _p(deltas), _p(weights_sum), _p(depth), _p(image), _p(normal))
+
+
+def composite_sdf_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                       T_thresh=1e-2):
+    sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
+    lib().ref_composite_sdf_rays(u32(n_alive), u32(n_step), f32(T_thresh), _p(rays_alive), _p(rays_t), _p(sigmas),
+                                 _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image))
+
+
+# ----------------------------------------------------------------------------- hash grid (tcnn restatement)
+
+
+class GridConfig:
+    """encoding_config of network_tcnn.py:56-63."""
+
+    def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                 per_level_scale=None, bound=1.0):
+        assert n_features_per_level == 2
+        if per_level_scale is None:  # network_tcnn.py:52
+            per_level_scale = np.exp2(np.log2(2048 * bound / 16) / (16 - 1))
+        self.n_levels, self.F = n_levels, n_features_per_level
+        self.log2_hashmap_size, self.base_resolution = log2_hashmap_size, base_resolution
+        self.per_level_scale = float(np.float32(per_level_scale))
+        offs = np.zeros(n_levels + 1, np.uint32)
+        res = np.zeros(n_levels, np.uint32)
+        scales = np.zeros(n_levels, np.float32)
+        self.n_entries = int(lib().ref_hashgrid_levels(u32(n_levels), u32(base_resolution),
+                                                       f32(self.per_level_scale), u32(log2_hashmap_size), _p(offs),
+                                                       _p(res), _p(scales)))
+        self.offsets, self.resolutions, self.scales = offs, res, scales
+        self.n_params = self.n_entries * self.F
+        self.n_output_dims = n_levels * self.F
+
+    def _args(self):
+        return (u32(self.n_levels), u32(self.base_resolution), f32(self.per_level_scale),
+                u32(self.log2_hashmap_size))
+
+
+def hashgrid_forward(x01, params, cfg):
+    x01, params = _f(x01).reshape(-1, 3), _f(params)
+    assert params.size == cfg.n_params
+    n = x01.shape[0]
+    out = np.empty((n, cfg.n_output_dims), np.float32)
+    lib().ref_hashgrid_forward(_p(x01), u32(n), _p(params), *cfg._args(), _p(out))
+    return out
+
+
+def hashgrid_backward(x01, dout, cfg):
+    x01, dout = _f(x01).reshape(-1, 3), _f(dout)
+    n = x01.shape[0]
+    g = np.zeros(cfg.n_params, np.float32)
+    lib().ref_hashgrid_backward(_p(x01), u32(n), _p(dout), *cfg._args(), _p(g))
+    return g
+
+
+def hashgrid_indices(x01, cfg):
+    x01 = _f(x01).reshape(-1, 3)
+    n = x01.shape[0]
+    idx = np.empty((n, cfg.n_levels, 8), np.uint32)
+    w = np.empty((n, cfg.n_levels, 8), np.float32)
+    lib().ref_hashgrid_indices(_p(x01), u32(n), *cfg._args(), _p(idx), _p(w))
+    return idx, w
+
+
+# ----------------------------------------------------------------------------- field (network_tcnn.py)
+
+
+class FieldParams:
+    """Flat parameters of the reference NeRFNetwork: encoder.params + sigma_net.net.{l}.{weight,bias}."""
+
+    def __init__(self, cfg, num_layers=3, hidden_dim=64, bound=1.0, blob_density=5.0, blob_radius=0.1, seed=0):
+        self.cfg, self.num_layers, self.hidden_dim, self.bound = cfg, num_layers, hidden_dim, float(bound)
+        self.blob_density, self.blob_radius = float(blob_density), float(blob_radius)
+        rng = np.random.default_rng(seed)
+        self.params = rng.uniform(-1e-4, 1e-4, cfg.n_params).astype(np.float32)  # tcnn init range
+        self.W, self.B = [], []
+        dim_in = cfg.n_output_dims
+        for l in range(num_layers):
+            i = dim_in if l == 0 else hidden_dim
+            o = 4 if l == num_layers - 1 else hidden_dim
+            k = 1.0 / np.sqrt(i)  # nn.Linear default init range
+            self.W.append(rng.uniform(-k, k, (o, i)).astype(np.float32))
+            self.B.append(rng.uniform(-k, k, o).astype(np.float32))
+
+
+def field_density(x, fp, half_mode=False, return_raw=False):
+    """NeRFNetwork.common_forward (network_tcnn.py:102-112): x [n,3] -> sigma [n], albedo [n,3]."""
+    x = _f(x).reshape(-1, 3)
+    n = x.shape[0]
+    sigma, albedo, raw = np.empty(n, np.float32), np.empty((n, 3), np.float32), np.empty((n, 4), np.float32)
+    Wp = (C.c_void_p * fp.num_layers)(*[_p(w) for w in fp.W])
+    Bp = (C.c_void_p * fp.num_layers)(*[_p(b) for b in fp.B])
+    lib().ref_field_density(_p(x), u32(n), f32(fp.bound), _p(fp.params), *fp.cfg._args(), u32(fp.num_layers),
+                            u32(fp.hidden_dim), Wp, Bp, f64(fp.blob_density), f64(fp.blob_radius),
+                            C.c_int(1 if half_mode else 0), _p(sigma), _p(albedo), _p(raw))
+    return (sigma, albedo, raw) if return_raw else (sigma, albedo)
+
+
+STENCIL = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+
+
+def safe_normalize(v, eps=1e-20):
+    """nerf/utils.py:47-48"""
+    return v / np.sqrt(np.clip((v * v).sum(-1, keepdims=True), eps, 1e32)).astype(np.float32)
+
+
+def field_stencil_sigmas(x, fp, epsilon=1e-2, half_mode=False):
+    """sigma at the six points of finite_difference_normal (network_tcnn.py:117-122): [n,6] (+x,-x,+y,-y,+z,-z)."""
+    x = _f(x).reshape(-1, 3)
+    out = np.empty((x.shape[0], 6), np.float32)
+    eps = np.float32(epsilon)
+    for j in range(6):
+        pj = np.clip(x + STENCIL[j] * eps, -fp.bound, fp.bound).astype(np.float32)
+        out[:, j] = field_density(pj, fp, half_mode)[0]
+    return out
+
+
+def normal_from_stencil(s6, epsilon=1e-2):
+    """network_tcnn.py:124-138: -[0.5*(s+ - s-)/eps] -> safe_normalize -> nan_to_num."""
+    eps = np.float32(epsilon)
+    with np.errstate(all="ignore"):
+        g = np.stack([np.float32(0.5) * (s6[:, 0] - s6[:, 1]) / eps, np.float32(0.5) * (s6[:, 2] - s6[:, 3]) / eps,
+                      np.float32(0.5) * (s6[:, 4] - s6[:, 5]) / eps], -1).astype(np.float32)
+        n = safe_normalize(-g)
+    return np.nan_to_num(n).astype(np.float32)
+
+
+def field_normal(x, fp, half_mode=False):
+    return normal_from_stencil(field_stencil_sigmas(x, fp, half_mode=half_mode))
+
+
+def field_forward(x, d, fp, light_d=None, ratio=1.0, shading="albedo", half_mode=False):
+    """NeRFNetwork.forward (network_tcnn.py:140-170)."""
+    sigma, albedo = field_density(x, fp, half_mode)
+    normal = field_normal(x, fp, half_mode)
+    if shading == "albedo" or normal.shape[0] >= 1e6:  # :146-150 and the silent skip at :159,:167-168
+        color = albedo
+    else:
+        lam = np.float32(ratio) + np.float32(1 - ratio) * np.clip(normal @ _f(light_d), 0.1, None)
+        if shading == "textureless":
+            color = np.repeat(lam[:, None], 3, 1)
+        elif shading == "normal":
+            color = (normal + 1) / 2
+        else:
+            color = albedo * lam[:, None]
+    return sigma, color.astype(np.float32), normal

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/mi3d.h declares.
+(No compute calls - there is no GPU in the build container.)"""
+import ctypes
+import os
+import re
+
+from conftest import PKG, ROOT
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "mi3d.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi3d_[A-Za-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mi3d_build", os.path.join(PKG, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    so = b.build()
+    assert os.path.exists(so)
+    lib = ctypes.CDLL(so)
+    names = _declared()
+    assert len(names) >= 19
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.mi3d_abi_version() == 1
+
+
+def test_python_binding_covers_the_abi():
+    from mi3d import _lib
+    lib = _lib.lib()
+    declared = set(_declared())
+    bound = set(_lib._SIGNATURES) | {"mi3d_abi_version", "mi3d_last_error_string", "mi3d_hashgrid_levels"}
+    bound |= set(getattr(_lib, "_LATE_SIGNATURES", {}))
+    assert declared <= bound, declared - bound
+    for n in bound:
+        assert hasattr(lib, n)
+
+
+def test_level_table_host_side(oracle):
+    import numpy as np
+    import tinycudann as tcnn
+    total, offs, res, scl = tcnn.grid_levels(16, 16, float(np.float32(1.3819128274917603)), 19)
+    assert total == 6098120 and total * 2 == 12196240  # 48.8 MB of fp32
+    assert list(res[:6]) == [16, 23, 31, 43, 59, 81] and res[-1] == 2048
+    cfg = oracle.GridConfig()
+    assert np.array_equal(offs, cfg.offsets) and np.array_equal(scl, cfg.scales)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(PKG):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                s = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) or "liboracle" in s:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
