@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""SDS train-steps/sec of Make-It-3D's coarse stage on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2_dense|c2_pruned|c4_pruned|small]
+
+One step = one pass of the hot path over one novel view (BASELINE config 2): 128x128 rays, max_steps 1024,
+16-level hash grid + 3x64 MLP (fp16 autocast), march -> 13-point field -> composite, SD2-base-shaped U-Net noise
+prediction (batch 2, CFG) + VAE encode, SDS gradient + regularisers, backward, clip, Adan step.  Synthetic rays from the
+reference's orbit poses, random-init weights, analytic occupancy (dense = all ones: every ray emits ~664 samples,
+m ~ 10.9 M samples/step).  Inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own view (phi = 30 + 45 k
+degrees) and the NeRF gradients are averaged with one flat RCCL all-reduce per step; `value` counts view-steps of all
+ranks per second (weak scaling).
+
+The JSON line also carries
+  roofline     : the dominant kernel (hash-grid gradient scatter, `k_scatter`) - algorithmic bytes per launch
+                 (2048 B per encoder evaluation = 16 levels x 8 corners x 2 floats, read-modify-write)
+                 over its average launch duration measured with HIP events on the launch stream during the timed steps;
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) rendering a bounded ray sample of the
+                 same workload on this box's host cores, extrapolated to a full view (forward render only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "make-it-3d_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (H, W, max_steps, bitfield, views_per_rank)
+    "c2_dense": dict(H=128, W=128, max_steps=1024, bitfield="dense"),
+    "c2_pruned": dict(H=128, W=128, max_steps=1024, bitfield=0.3),
+    "c4_pruned": dict(H=256, W=256, max_steps=2048, bitfield=0.5),
+    "small": dict(H=32, W=32, max_steps=128, bitfield="dense"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+SCATTER_BYTES_PER_EVAL = 2048
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """Oracle (CPU port) forward render of a ray sample of this workload; returns the cpu_baseline object."""
+    import numpy as np
+    from mi3d import rays as R
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ro, rd, _ = R.view_rays(wl["H"], wl["W"])
+    o, d = ro.view(-1, 3).numpy(), rd.view(-1, 3).numpy()
+    N = o.shape[0]
+    cfg = O.GridConfig()
+    fp = O.FieldParams(cfg)
+    bits = np.full(128 ** 3 // 8, 255, np.uint8)
+    if wl["bitfield"] != "dense":
+        co = np.stack(np.meshgrid(*[np.arange(128)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+        grid = np.zeros((1, 128 ** 3), np.float32)
+        grid[0, O.morton3D(co)] = np.linalg.norm((co + 0.5) / 128 * 2 - 1, axis=1) < float(wl["bitfield"])
+        bits = O.packbits(grid, 0.5)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+
+    def render(idx):
+        nears, fars = O.near_far_from_aabb(o[idx], d[idx], aabb)
+        xyzs, dirs, deltas, rays = O.march_rays_train(o[idx], d[idx], 1.0, bits, 1, 128, nears, fars, align=128,
+                                                      max_steps=wl["max_steps"])
+        sig, col, nrm = O.field_forward(xyzs, dirs, fp)           # 7 field evaluations per sample
+        O.field_normal(xyzs + np.float32(0.01), fp)               # + 6 for the smoothness term = 13
+        O.composite_rays_train(sig, col, deltas, rays)
+        return xyzs.shape[0]
+
+    rng = np.random.default_rng(0)
+    n = 32
+    t0 = time.perf_counter()
+    render(rng.choice(N, n, replace=False))
+    dt = time.perf_counter() - t0
+    n = int(min(N, max(32, n * budget_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    m = render(rng.choice(N, n, replace=False))
+    dt = time.perf_counter() - t0
+    return {"value": (n / N) / dt, "unit": "render-steps/s (forward only)", "cores": cores, "kind": "port",
+            "sample": f"{n} of {N} rays ({m} samples, 13 field evaluations each) of the same view, "
+                      f"oracle march+field+composite, {dt:.1f} s, extrapolated to the full view"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2_dense", choices=list(WORKLOADS))
+    ap.add_argument("--sds-backward", default="single", choices=["single", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    wl = WORKLOADS[args.workload]
+
+    from mi3d import dp, grid_ops, rays as R, sd_standin, sds_step
+    opt = sds_step.make_opt(max_steps=wl["max_steps"])
+    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"])
+    dp.broadcast_module_state(model)
+    bucket = dp.FlatGradBucket(model.parameters())
+    guidance = sd_standin.StableDiffusionStandIn(dev)
+    text_z = guidance.get_text_embeds()
+    ro, rd, ds = R.view_rays(wl["H"], wl["W"], view=rank, device=dev)
+    t_fixed = torch.tensor([400], dtype=torch.long, device=dev)  # t fixed for timing
+    torch.manual_seed(1234 + rank)
+
+    def step():
+        bucket.zero()
+        return sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
+                                       sds_backward=args.sds_backward, t=t_fixed, grad_sync=bucket.all_reduce_mean)
+
+    for _ in range(args.warmup):
+        step()
+    grid_ops.PROFILE = {"scatter": [], "encode": []}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, grid_ops.PROFILE = grid_ops.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
+    if rank == 0:
+        sc = [a.elapsed_time(b) for a, b in prof["scatter"]]
+        en = [a.elapsed_time(b) for a, b in prof["encode"]]
+        evals = [e for e in prof.get("scatter_evals", [])]
+        sc_ms = sum(sc) / max(len(sc), 1)
+        P = 13
+        alg_bytes = (sum(evals) / max(len(evals), 1)) * SCATTER_BYTES_PER_EVAL if evals else m * P * SCATTER_BYTES_PER_EVAL
+        achieved = alg_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
+        line = {
+            "metric": "SDS train-steps/sec (NeRF render+SD U-Net fwd+bwd) @128x128",
+            "value": world * args.steps / elapsed, "unit": "view-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 grid + f16 MLP (autocast), f16 U-Net",
+            "data": "synthetic (reference orbit rays, random-init weights, analytic occupancy)",
+            "config": {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
+                                   f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step, occupancy "
+                                   f"{wl['bitfield']}, {m} samples/view x 13 field evaluations",
+                       "views_per_step": world, "sds_backward": args.sds_backward,
+                       "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad all-reduce)"},
+            "roofline": {"kernel": "k_scatter (hash-grid gradient scatter, fp32 atomics)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "launches": len(sc), "avg_launch_ms": sc_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "true bound is the L2 atomic request rate (~21 G 64-B requests/s, "
+                                 "profiles/atomics_r01.txt), not HBM bandwidth; see DESIGN.md"},
+            "kernels_ms_per_step": {"k_scatter": sum(sc) / args.steps, "k_grid_encode": sum(en) / args.steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(wl)
+            except Exception as e:  # the baseline leg must never take the bench line down with it
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

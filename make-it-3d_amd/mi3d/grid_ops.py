@@ -21,6 +21,22 @@ def stencil_offsets(center=True, second=False):
     return offs, (P0 if second else offs.shape[0])
 
 
+# bench.py sets this to {"scatter": [], "encode": []} to collect HIP-event pairs around the two grid kernels
+# (events are recorded on torch's current stream, the stream the C ABI launches on).
+PROFILE = None
+
+
+def _timed(kind, launch, evals):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE[kind].append((e0, e1))
+    PROFILE.setdefault(kind + "_evals", []).append(evals)
+
+
 def _offs_arg(offsets):
     offsets = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1, 3)
     return offsets, offsets.ctypes.data_as(C.c_void_p)
@@ -39,9 +55,10 @@ class _EncodePoints(Function):
         out = torch.empty(n * P, cfg["n_levels"] * 2, dtype=torch.float32, device=x.device)
         if count is not None:  # rows past *count are not written by the kernel
             out.zero_()
-        L.call("mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
-               L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"],
-               cfg["log2_hashmap_size"], L.ptr(out), L.stream())
+        _timed("encode", lambda: L.call(
+            "mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
+            L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"],
+            L.ptr(out), L.stream()), n * P)
         ctx.save_for_backward(x, x2 if x2 is not None else x, count if count is not None else x)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, count is not None, params.numel())
         return out
@@ -54,10 +71,11 @@ class _EncodePoints(Function):
         dout = L.dev_f32(dout.float().contiguous(), "dout")
         grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
         _, offs_p = _offs_arg(offs)
-        L.call("mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
-               L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
-               cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad),
-               L.stream())
+        _timed("scatter", lambda: L.call(
+            "mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
+            L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
+            cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad), L.stream()),
+            x.shape[0] * offs.shape[0])
         return grad, None, None, None, None, None, None, None, None
 
 

@@ -1,0 +1,306 @@
+"""NeRFRenderer - the reference's `nerf.renderer.NeRFRenderer` surface (/root/reference/nerf/renderer.py:99-677)
+on the MI355X kernels: same constructor, buffers (state_dict keys aabb_train / aabb_infer / density_grid /
+density_bitfield / step_counter), attributes and `render / run / run_cuda / update_extra_state` semantics.
+
+What differs is how the work is issued, not what is computed:
+  * training `run_cuda` asks the field for the whole 13-point stencil of every sample at once
+    (`self.field_stencil`) instead of 13 separate `self(...)` / `self.normal(...)` passes;
+  * RNG draws happen in the reference's order (light direction, march noise, smoothness jitter) so a
+    seeded run sees the same random numbers.
+`export_mesh` (marching cubes + xatlas + nvdiffrast, renderer.py:142-330) is outside the hot path and not provided.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+import raymarching
+
+
+def safe_normalize(x, eps=1e-20):
+    # nerf/utils.py:47-48
+    return x / torch.sqrt(torch.clamp(torch.sum(x * x, -1, keepdim=True), min=eps, max=1e32))
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF resampling of `bins` [B,T] by `weights` [B,T-1] (renderer.py:16-50)."""
+    weights = weights + 1e-5
+    pdf = weights / weights.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(*cdf.shape[:-1], n_samples)
+    else:
+        u = torch.rand(*cdf.shape[:-1], n_samples).to(weights.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    denom = c_hi - c_lo
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return b_lo + (u - c_lo) / denom * (b_hi - b_lo)
+
+
+def near_far_from_bound(rays_o, rays_d, bound, type="cube", min_near=0.05):
+    """renderer.py:52-76 (fp32 regardless of autocast)."""
+    with torch.autocast("cuda", enabled=False):
+        radius = rays_o.norm(dim=-1, keepdim=True)
+        if type == "sphere":
+            return radius - bound, radius + bound
+        tmin = (-bound - rays_o) / (rays_d + 1e-15)
+        tmax = (bound - rays_o) / (rays_d + 1e-15)
+        near = torch.where(tmin < tmax, tmin, tmax).max(dim=-1, keepdim=True)[0]
+        far = torch.where(tmin > tmax, tmin, tmax).min(dim=-1, keepdim=True)[0]
+        miss = far < near
+        near[miss] = 1e9
+        far[miss] = 1e9
+        return torch.clamp(near, min=min_near), far
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.bound = opt.bound
+        self.cascade = 1 + math.ceil(math.log2(opt.bound))
+        self.grid_size = 128
+        self.cuda_ray = opt.cuda_ray
+        self.min_near = opt.min_near
+        self.density_thresh = opt.density_thresh
+        self.bg_radius = opt.bg_radius
+
+        box = torch.FloatTensor([-opt.bound, -opt.bound, -opt.bound, opt.bound, opt.bound, opt.bound])
+        self.register_buffer("aabb_train", box)
+        self.register_buffer("aabb_infer", box.clone())
+        if self.cuda_ray:
+            self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer("density_bitfield",
+                                 torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    # --- the field interface subclasses provide -------------------------------------------------
+    def forward(self, x, d, l=None, ratio=1, shading="albedo"):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def normal(self, x):
+        raise NotImplementedError()
+
+    def field_stencil(self, x, x2=None, step=0.0):
+        """sigma [m], albedo [m,3], normal(x) [m,3], normal(x2) [m,3] or None - all stencil points in one pass."""
+        raise NotImplementedError()
+
+    def shade(self, albedo, normal, light_d, ratio, shading):
+        raise NotImplementedError()
+
+    # --- pure-PyTorch sampler path (BASELINE config 1) --------------------------------------------
+    def run(self, rays_o, rays_d, ref_bg=None, num_steps=128, upsample_steps=128, light_d=None, ambient_ratio=1.0,
+            shading="albedo", bg_color=None, perturb=False, **kwargs):
+        """Uniform + importance sampling between the bounding-sphere hits, alpha compositing without early
+        termination (renderer.py:332-479).  rays [B,N,3] with B == 1; bg_color [B*N,3] or None."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        out = {}
+
+        nears, fars = near_far_from_bound(rays_o, rays_d, self.bound, type="sphere", min_near=self.min_near)
+        if light_d is None:
+            light_d = safe_normalize(rays_o[0] + torch.randn(3, device=device, dtype=torch.float))
+
+        z = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0)  # [N,T]
+        spacing = (fars - nears) / num_steps
+        if perturb:
+            z = z + (torch.rand(z.shape, device=device) - 0.5) * spacing
+
+        def positions(zv):
+            p = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * zv.unsqueeze(-1)
+            return torch.min(torch.max(p, aabb[:3]), aabb[3:])
+
+        def weights_of(zv, sigma):
+            delta = torch.cat([zv[..., 1:] - zv[..., :-1], spacing * torch.ones_like(zv[..., :1])], -1)
+            alpha = 1 - torch.exp(-delta * sigma)
+            trans = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-15], -1), -1)[..., :-1]
+            return alpha * trans, delta
+
+        xyzs = positions(z)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+
+        if upsample_steps > 0:
+            with torch.no_grad():
+                w, delta = weights_of(z, dens["sigma"].squeeze(-1))
+                mid = z[..., :-1] + 0.5 * delta[..., :-1]
+                z_new = sample_pdf(mid, w[:, 1:-1], upsample_steps, det=not self.training).detach()
+                xyzs_new = positions(z_new)
+            dens_new = {k: v.view(N, upsample_steps, -1) for k, v in self.density(xyzs_new.reshape(-1, 3)).items()}
+            z, order = torch.sort(torch.cat([z, z_new], 1), dim=1)
+            xyzs = torch.cat([xyzs, xyzs_new], 1)
+            xyzs = torch.gather(xyzs, 1, order.unsqueeze(-1).expand_as(xyzs))
+            for k in dens:
+                both = torch.cat([dens[k], dens_new[k]], 1)
+                dens[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+
+        weights, _ = weights_of(z, dens["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), light_d, ratio=ambient_ratio,
+                                     shading=shading)
+        rgbs = rgbs.view(N, -1, 3)
+        normal_map = None
+        if normals is not None:
+            normals = normals.view(N, -1, 3)
+            normal_map = torch.sum(normals * weights[:, :, None], dim=1)
+            out["loss_orient"] = (weights.detach() * (normals * dirs).sum(-1).clamp(min=0) ** 2).sum(-1).mean()
+            if self.opt.lambda_smooth > 0:
+                jitter = self.normal(xyzs.reshape(-1, 3) + torch.randn_like(xyzs).reshape(-1, 3) * 1e-2)
+                out["loss_smooth"] = (normals - jitter.view(N, -1, 3)).abs().mean()
+
+        weights_sum = weights.sum(-1)
+        depth = torch.sum(weights * z, -1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+
+        out["image"] = image.view(*prefix, 3)
+        out["depth"] = depth.view(*prefix, 1)
+        out["weights_sum"] = weights_sum
+        out["mask"] = (nears < fars).reshape(*prefix)
+        out["normal"] = normal_map
+        return out
+
+    # --- occupancy-grid path (the hot path) ------------------------------------------------------------
+    def run_cuda(self, rays_o, rays_d, depth_scale=None, bg_color=None, dt_gamma=0, light_d=None, ambient_ratio=1.0,
+                 shading="albedo", perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
+        """renderer.py:481-583.  Training: march -> field (13-point stencil) -> composite + normal regularisers.
+        Eval: the march/composite loop over alive rays."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+
+        # min_near is NOT forwarded here by the reference either: near_far_from_aabb's own default 0.2 applies
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
+        if light_d is None:
+            light_d = safe_normalize(rays_o[0] + torch.randn(3, device=device, dtype=torch.float))
+        out = {}
+
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+                rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
+                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+            smooth = self.opt.lambda_smooth > 0
+            x2 = xyzs + torch.randn_like(xyzs) * 1e-2 if smooth else None
+            step = 2 * math.sqrt(3) / max_steps  # dt_min: only steers the scatter's merge heuristic
+            sigmas, albedo, normals, normals_jitter = self.field_stencil(xyzs, x2, step)
+            rgbs = self.shade(albedo, normals, light_d, ambient_ratio, shading)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            if normals is not None:
+                w = 1 - torch.exp(-sigmas)  # "not very exact in cuda ray mode": per-sample opacity proxy
+                out["loss_orient"] = (w.detach() * (normals * dirs).sum(-1).clamp(min=0) ** 2).mean()
+                if smooth:
+                    out["loss_smooth"] = (normals - normals_jitter).abs().mean()
+        else:
+            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+            depth = torch.zeros(N, dtype=torch.float32, device=device)
+            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+            normal = torch.zeros(N, 3, dtype=torch.float32, device=device)
+            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step = 0
+            while step < max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
+                                                            self.bound, self.density_bitfield, self.cascade,
+                                                            self.grid_size, nears, fars, 128,
+                                                            perturb if step == 0 else False, dt_gamma, max_steps)
+                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, (normals + 1) / 2,
+                                           deltas, weights_sum, depth, image, normal, T_thresh)
+                rays_alive = rays_alive[rays_alive >= 0]
+                step += n_step
+
+        if bg_color is None:
+            bg_color = 1
+        image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+        if not self.training:
+            normal = (normal + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+        depth = depth + (1 - weights_sum) * self.opt.max_depth
+        depth = depth.view(*prefix, 1)
+        if depth_scale is not None:
+            depth = depth * depth_scale.view(*prefix, 1)
+
+        out["image"] = image
+        out["depth"] = depth
+        out["weights_sum"] = weights_sum.reshape(*prefix)
+        out["mask"] = (nears < fars).reshape(*prefix)
+        if not self.training:
+            out["normal"] = normal
+        return out
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """Density-grid refresh (renderer.py:586-639): jittered cell-centre densities per cascade, EMA-max, mean
+        threshold, repack the bitfield; refresh mean_count."""
+        if not self.cuda_ray:
+            return
+        dev = self.aabb_train.device
+        fresh = -torch.ones_like(self.density_grid)
+        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev)
+        for xs in axis.split(S):
+            for ys in axis.split(S):
+                for zs in axis.split(S):
+                    gx, gy, gz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], -1)
+                    slots = raymarching.morton3D(coords).long()
+                    centres = 2 * coords.float() / (self.grid_size - 1) - 1
+                    for cas in range(self.cascade):
+                        span = min(2 ** cas, self.bound)
+                        half = span / self.grid_size
+                        pts = centres * (span - half)
+                        pts += (torch.rand_like(pts) * 2 - 1) * half
+                        fresh[cas, slots] = self.density(pts)["sigma"].reshape(-1).detach().float()
+        live = self.density_grid >= 0
+        self.density_grid[live] = torch.maximum(self.density_grid[live] * decay, fresh[live])
+        self.mean_density = torch.mean(self.density_grid[live]).item()
+        self.iter_density += 1
+        thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
+        total = min(16, self.local_step)
+        if total > 0:
+            self.mean_count = int(self.step_counter[:total, 0].sum().item() / total)
+        self.local_step = 0
+
+    def render(self, rays_o, rays_d, depth_scale=None, staged=False, max_ray_batch=4096, **kwargs):
+        """renderer.py:642-677: dispatch to run_cuda / run; `staged` chunks rays on the non-cuda_ray path only."""
+        if self.cuda_ray:
+            return self.run_cuda(rays_o, rays_d, depth_scale, **kwargs)
+        if not staged:
+            return self.run(rays_o, rays_d, depth_scale, **kwargs)
+        B, N = rays_o.shape[:2]
+        dev = rays_o.device
+        depth = torch.empty((B, N, 1), device=dev)
+        image = torch.empty((B, N, 3), device=dev)
+        weights_sum = torch.empty((B, N), device=dev)
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                part = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                depth[b:b + 1, head:tail] = part["depth"]
+                weights_sum[b:b + 1, head:tail] = part["weights_sum"]
+                image[b:b + 1, head:tail] = part["image"]
+        return {"depth": depth, "image": image, "weights_sum": weights_sum}

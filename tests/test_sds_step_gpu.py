@@ -1,0 +1,97 @@
+"""GPU: the SDS training step (mi3d.sds_step) - both backward schedules give the same parameter gradients, a step
+changes the parameters, fp16 autocast stays finite."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, seed=0, fp16=True):
+    from mi3d import rays as R, sd_standin, sds_step
+    opt = sds_step.make_opt(max_steps=64, fp16=fp16)
+    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=seed, bitfield=0.5)
+    with torch.no_grad():
+        model.encoder.params.uniform_(-0.1, 0.1)
+    ro, rd, ds = R.view_rays(32, 32, device=dev)
+    return opt, model, optimizer, scaler, (ro, rd, ds)
+
+
+class _TinyGuidance(torch.nn.Module):
+    """A small conv stand-in so the test is fast; same sds_gradient/train_step contract as the SD stand-in."""
+
+    def __init__(self, dev, deterministic=False):
+        super().__init__()
+        from mi3d.sd_standin import StableDiffusionStandIn
+        self.impl = StableDiffusionStandIn.__new__(StableDiffusionStandIn)
+        torch.nn.Module.__init__(self.impl)
+        from mi3d import sd_standin as S
+        torch.manual_seed(0)
+        self.impl.device = dev
+        if deterministic:  # backward-schedule equivalence must not depend on which conv solver MIOpen picks
+            class _U(torch.nn.Module):
+                def __init__(s):
+                    super().__init__()
+                    s.conv_in = torch.nn.Conv2d(4, 4, 1)
+
+                def forward(s, x, t, encoder_hidden_states):
+                    return torch.tanh(0.7 * x + 0.1 * encoder_hidden_states.float().mean())
+
+            class _V(torch.nn.Module):
+                def forward(s, x):
+                    p = torch.nn.functional.avg_pool2d(x, 8)
+                    return torch.cat([p, p[:, :1], 0.1 * p, 0.1 * p[:, :1]], 1)
+            self.impl.unet, self.impl.vae_encoder = _U().to(dev), _V().to(dev)
+        else:
+            self.impl.unet = S.UNetSD2(ch=(64, 128, 128, 128), ctx_dim=64).to(dev).half()
+            self.impl.vae_encoder = S.VAEEncoderSD(ch=(32, 32, 64, 64)).to(dev)
+        for p in self.impl.parameters():
+            p.requires_grad_(False)
+        self.impl.num_train_timesteps, self.impl.min_step, self.impl.max_step = 1000, 200, 600
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+        self.impl.register_buffer("alphas", torch.cumprod(1 - betas, 0).to(dev), persistent=False)
+
+    def __getattr__(self, k):
+        if k == "impl":
+            return super().__getattr__(k)
+        return getattr(self.impl, k)
+
+
+def test_single_backward_equals_reference_two_backward(cuda):
+    from mi3d import sds_step
+    grads = {}
+    for mode in ("reference", "single"):
+        opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=False)
+        guidance = _TinyGuidance(cuda, deterministic=True)
+        text_z = torch.randn(2, 77, 64, generator=torch.Generator().manual_seed(1)).to(cuda)
+        captured = {}
+        orig = torch.nn.utils.clip_grad_norm_
+        torch.nn.utils.clip_grad_norm_ = lambda params, max_norm: captured.update(
+            {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+        try:
+            torch.manual_seed(5)
+            sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt,
+                                    sds_backward=mode, t=torch.tensor([400], device=cuda))
+        finally:
+            torch.nn.utils.clip_grad_norm_ = orig
+        grads[mode] = captured
+    for n in grads["single"]:
+        a, b = grads["single"][n], grads["reference"][n]
+        assert torch.isfinite(a).all()
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 1e-3 * scale, n
+
+
+def test_fp16_step_updates_parameters_and_stays_finite(cuda):
+    from mi3d import sds_step
+    opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=True)
+    guidance = _TinyGuidance(cuda)
+    text_z = torch.randn(2, 77, 64, device=cuda)
+    before = model.encoder.params.detach().clone()
+    w0 = model.sigma_net.net[0].weight.detach().clone()
+    for _ in range(3):
+        loss = sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt)
+        assert torch.isfinite(loss)
+    assert torch.isfinite(model.encoder.params).all()
+    assert float((model.encoder.params - before).abs().max()) > 0
+    assert float((model.sigma_net.net[0].weight - w0).abs().max()) > 0
