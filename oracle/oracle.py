@@ -315,3 +315,70 @@ def field_forward(x, d, fp, light_d=None, ratio=1.0, shading="albedo", half_mode
         else:
             color = albedo * lam[:, None]
     return sigma, color.astype(np.float32), normal
+
+
+# ----------------------------------------------------------------------------- pure-PyTorch sampler path (config 1)
+
+
+def sample_pdf_det(bins, weights, n_samples):
+    """renderer.py:16-50 with det=True (eval mode): inverse-CDF resampling at the n bin mid-quantiles."""
+    weights = weights.astype(np.float32) + np.float32(1e-5)
+    pdf = weights / weights.sum(-1, keepdims=True)
+    cdf = np.concatenate([np.zeros_like(pdf[:, :1]), np.cumsum(pdf, -1, dtype=np.float32)], -1)
+    u = np.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, n_samples, dtype=np.float32)
+    out = np.empty((bins.shape[0], n_samples), np.float32)
+    for b in range(bins.shape[0]):
+        inds = np.searchsorted(cdf[b], u, side="right")
+        below = np.maximum(inds - 1, 0)
+        above = np.minimum(inds, cdf.shape[-1] - 1)
+        c0, c1 = cdf[b, below], cdf[b, above]
+        b0, b1 = bins[b, below], bins[b, above]
+        denom = c1 - c0
+        denom = np.where(denom < 1e-5, np.float32(1), denom)
+        out[b] = b0 + (u - c0) / denom * (b1 - b0)
+    return out
+
+
+def render_run(rays_o, rays_d, fp, num_steps=64, upsample_steps=0, light_d=None, ratio=1.0, shading="albedo",
+               bg_color=1.0, min_near=0.1):
+    """NeRFRenderer.run in eval mode, perturb off (renderer.py:332-479): sphere near/far, uniform (+ deterministic
+    importance) samples, alpha compositing WITHOUT early termination, depth = sum w z."""
+    o, d = _f(rays_o).reshape(-1, 1, 3), _f(rays_d).reshape(-1, 1, 3)
+    N, b = o.shape[0], np.float32(fp.bound)
+    radius = np.sqrt((o * o).sum(-1)).astype(np.float32)  # [N,1]
+    nears, fars = radius - b, radius + b                   # type='sphere' (:350); min_near unused for spheres
+    z = (nears + (fars - nears) * np.linspace(0, 1, num_steps, dtype=np.float32)[None]).astype(np.float32)
+    spacing = ((fars - nears) / np.float32(num_steps)).astype(np.float32)
+
+    def positions(zv):
+        return np.clip(o + d * zv[..., None], -b, b).astype(np.float32)
+
+    def weights_of(zv, sigma):
+        delta = np.concatenate([zv[:, 1:] - zv[:, :-1], spacing * np.ones_like(zv[:, :1])], -1)
+        alpha = (1 - np.exp(-delta * sigma)).astype(np.float32)
+        shifted = np.concatenate([np.ones_like(alpha[:, :1]), 1 - alpha + np.float32(1e-15)], -1)
+        return alpha * np.cumprod(shifted, -1, dtype=np.float32)[:, :-1], delta
+
+    xyzs = positions(z)
+    sigma = field_density(xyzs.reshape(-1, 3), fp)[0].reshape(N, -1)
+    if upsample_steps > 0:
+        w, delta = weights_of(z, sigma)
+        mid = z[:, :-1] + np.float32(0.5) * delta[:, :-1]
+        z_new = sample_pdf_det(mid, w[:, 1:-1], upsample_steps)
+        xyz_new = positions(z_new)
+        sig_new = field_density(xyz_new.reshape(-1, 3), fp)[0].reshape(N, -1)
+        z_all = np.concatenate([z, z_new], 1)
+        order = np.argsort(z_all, 1, kind="stable")
+        z = np.take_along_axis(z_all, order, 1)
+        xyzs = np.take_along_axis(np.concatenate([xyzs, xyz_new], 1), order[..., None], 1)
+        sigma = np.take_along_axis(np.concatenate([sigma, sig_new], 1), order, 1)
+    weights, _ = weights_of(z, sigma)
+    T_ = z.shape[1]
+    dirs = np.broadcast_to(d, (N, T_, 3)).reshape(-1, 3)
+    _, rgbs, normals = field_forward(xyzs.reshape(-1, 3), dirs, fp, light_d, ratio, shading)
+    ws = weights.sum(-1)
+    depth = (weights * z).sum(-1)
+    image = (weights[..., None] * rgbs.reshape(N, T_, 3)).sum(1) + (1 - ws)[:, None] * np.float32(bg_color)
+    normal_map = (normals.reshape(N, T_, 3) * weights[..., None]).sum(1)
+    return dict(image=image.astype(np.float32), depth=depth.astype(np.float32), weights_sum=ws.astype(np.float32),
+                normal=normal_map.astype(np.float32))
