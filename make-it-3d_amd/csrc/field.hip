@@ -1,0 +1,506 @@
+// The field's MLP on the MI355X matrix cores: Linear(32,64)-ReLU-Linear(64,64)-ReLU-Linear(64,4), forward and
+// backward (input gradient + all weight/bias gradients) in ONE kernel each, activations never leave registers.
+// Replaces the three nn.Linear / two ReLU launches per field evaluation of the reference's `sigma_net`
+// (/root/reference/nerf/network_tcnn.py:13-32,67,107) - Part 4 of include/mi3d.h.
+//
+// Dataflow (wave64, v_mfma_f32_32x32x16_f16 or, in exact-fp32 mode, v_mfma_f32_32x32x2_f32).  One wave owns a
+// TILE of 32 rows (field evaluations).  Every matrix product is D = A.B with a 32x32 output tile whose lane l holds
+// column (l & 31) and, in register q, row rowmap(q, l >> 5) = (q & 3) + 8 (q >> 2) + 4 (l >> 5).  A "K-block" is 32
+// contraction indices held as 16 values per lane: value q of lane-half h stands for index kmap(q, h).  Two facts
+// make the whole network chain through registers with no LDS round trip and no cross-lane traffic:
+//   (1) the hardware pairs A and B by K-SLOT, so any kmap works as long as both operands use it - in particular
+//       kmap = rowmap: the accumulators of one layer ARE the next layer's operand (after bias/ReLU/convert);
+//   (2) A and B fragments have the same lane layout (lane = row of A / column of B), so an activation tile held
+//       as "lane = sample, values = features" can be the B operand (output: lane = sample, rows = out features,
+//       "orientation 1") or the A operand (output: lane = out feature, rows = samples, "orientation 2").
+// Orientation 2 is what the weight gradients need (contraction over samples), so the backward kernel runs the
+// cheap 32-wide layers in both orientations instead of transposing tiles through LDS: 34 K-block products per tile
+// (64 MFMAs in fp16 mode, 2048 matrix-pipe cycles per 32 samples) - the kernel stays bound by streaming its rows.
+//
+// Weights live in LDS as ready-made operand blocks (one 16-byte vector per lane per read, conflict-free), built
+// once per workgroup from the fp32 master weights; fp16 mode rounds weights, biases and inter-layer activations to
+// binary16 exactly where torch.autocast does for nn.Linear (oracle/field_ref.c half_mode).
+//
+// Weight gradients accumulate in registers across all tiles of a persistent wave, are reduced across the
+// workgroup in LDS and leave with one atomic per element per workgroup.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mi3d.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerWG = 4;
+constexpr int DIN = 32, HID = 64, DOUT = 4;
+constexpr int NTH = HID / 32;  // 32-wide tiles across the hidden width
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ int rowmap(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------- precision policies
+struct F16 {
+    using elem = _Float16;
+    static constexpr int kUnits = 2;  // 16-byte vectors per lane per K-block (8 halfs each)
+    struct KB { half8 v[2]; };
+    __device__ static __forceinline__ float round(float x) { return (float)(_Float16)x; }
+    __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q >> 3][q & 7] = (_Float16)x; }
+    __device__ static __forceinline__ void mma(f32x16 &acc, const KB &a, const KB &b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[0], b.v[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[1], b.v[1], acc, 0, 0, 0);
+    }
+    // only values q < 8 of both operands are non-zero
+    __device__ static __forceinline__ void mma_lo(f32x16 &acc, const KB &a, const KB &b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[0], b.v[0], acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ KB load_block(const char *blk, int lane) {
+        KB k;
+        k.v[0] = *reinterpret_cast<const half8 *>(blk + (0 * kWave + lane) * 16);
+        k.v[1] = *reinterpret_cast<const half8 *>(blk + (1 * kWave + lane) * 16);
+        return k;
+    }
+};
+
+struct F32 {
+    using elem = float;
+    static constexpr int kUnits = 4;  // 4 floats each
+    struct KB { float v[16]; };
+    __device__ static __forceinline__ float round(float x) { return x; }
+    __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q] = x; }
+    __device__ static __forceinline__ void mma(f32x16 &acc, const KB &a, const KB &b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q], b.v[q], acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void mma_lo(f32x16 &acc, const KB &a, const KB &b) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q], b.v[q], acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ KB load_block(const char *blk, int lane) {
+        KB k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(blk + (u * kWave + lane) * 16);
+            k.v[4 * u] = t[0]; k.v[4 * u + 1] = t[1]; k.v[4 * u + 2] = t[2]; k.v[4 * u + 3] = t[3];
+        }
+        return k;
+    }
+};
+
+template <class P> constexpr int block_bytes() { return P::kUnits * kWave * 16; }
+
+// ---------------------------------------------------------------- operand blocks in LDS
+// Block list (N = the dimension lanes run over, K = the contraction dimension; kind D: kmap = rowmap, kind X:
+// kmap(q, h) = 16 h + q, the layout rows are loaded from memory in):
+enum : int {
+    B_W1 = 0,              // [tn]      N = hidden-1 feature, K = input feature (X)      Wm[N][K] = W1[N][K]
+    B_W2 = B_W1 + NTH,     // [tn][tk]  N = hidden-2 feature, K = hidden-1 feature (D)   W2[N][K]
+    B_W3 = B_W2 + NTH * NTH,   // [tk]  N = output (4, zero padded), K = hidden-2 (D)    W3[N][K]
+    B_W3T = B_W3 + NTH,    // [tn]      N = hidden-2 feature, K = output index (X, < 4)  W3[K][N]
+    B_W2T = B_W3T + NTH,   // [tn][tk]  N = hidden-1 feature, K = hidden-2 feature (D)   W2[K][N]
+    B_W1T = B_W2T + NTH * NTH, // [tk]  N = input feature, K = hidden-1 feature (D)      W1[K][N]
+    B_FWD_COUNT = B_W3T,
+    B_ALL_COUNT = B_W1T + NTH,
+};
+
+struct Weights {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+};
+
+template <class P>
+__device__ void build_blocks(char *lds, float *bias /* [HID + HID + 32] */, const Weights &w, int n_blocks) {
+    using T = typename P::elem;
+    for (int e = threadIdx.x; e < n_blocks * kWave * 16; e += blockDim.x) {
+        const int blk = e / (kWave * 16), r = e % (kWave * 16), lane = r / 16, q = r % 16;
+        const int nl = lane & 31, h = lane >> 5;
+        const int kd = rowmap(q, h), kx = 16 * h + q;
+        float v = 0.f;
+        if (blk < B_W2) {
+            const int tn = blk - B_W1;
+            v = w.W1[(32 * tn + nl) * DIN + kx];
+        } else if (blk < B_W3) {
+            const int tn = (blk - B_W2) / NTH, tk = (blk - B_W2) % NTH;
+            v = w.W2[(32 * tn + nl) * HID + 32 * tk + kd];
+        } else if (blk < B_W3T) {
+            const int tk = blk - B_W3;
+            v = nl < DOUT ? w.W3[nl * HID + 32 * tk + kd] : 0.f;
+        } else if (blk < B_W2T) {
+            const int tn = blk - B_W3T;
+            v = kx < DOUT ? w.W3[kx * HID + 32 * tn + nl] : 0.f;
+        } else if (blk < B_W1T) {
+            const int tn = (blk - B_W2T) / NTH, tk = (blk - B_W2T) % NTH;
+            v = w.W2[(32 * tk + kd) * HID + 32 * tn + nl];
+        } else {
+            const int tk = blk - B_W1T;
+            v = w.W1[(32 * tk + kd) * DIN + nl];
+        }
+        // value q of lane sits in 16-byte unit q / per_unit
+        constexpr int per_unit = 16 / (int)sizeof(T);
+        T *dst = reinterpret_cast<T *>(lds + (size_t)blk * block_bytes<P>() + ((q / per_unit) * kWave + lane) * 16);
+        dst[q % per_unit] = (T)v;
+    }
+    for (int e = threadIdx.x; e < HID + HID + 32; e += blockDim.x) {
+        float v = 0.f;
+        if (e < HID) v = w.b1[e];
+        else if (e < 2 * HID) v = w.b2[e - HID];
+        else if (e - 2 * HID < DOUT) v = w.b3[e - 2 * HID];
+        bias[e] = P::round(v);
+    }
+}
+
+// ---------------------------------------------------------------- tile pieces
+// rows of the tile as a K-block (kind X): lane (p, h) holds features 16 h .. 16 h + 15 of row row0 + p
+template <class P>
+__device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, bool valid, int h) {
+    typename P::KB k;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (valid) t = src[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) P::set(k, 4 * c + i, t[i]);
+    }
+    return k;
+}
+
+// [rows,4] output-side gradient as a K-block (kind X over the 4 outputs): only lane-half 0, q < 4 are non-zero
+template <class P>
+__device__ __forceinline__ typename P::KB load_dout_kb(const float *__restrict__ dout, size_t row, bool valid, int h) {
+    typename P::KB k;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (valid && h == 0) t = *reinterpret_cast<const f32x4 *>(dout + row * DOUT);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) P::set(k, q, q < 4 ? t[q] : 0.f);
+    return k;
+}
+
+// accumulator tile -> K-block (kind D) with ReLU; also returns the >0 mask (bit q)
+template <class P>
+__device__ __forceinline__ typename P::KB relu_kb(const f32x16 &acc, uint32_t &mask) {
+    typename P::KB k;
+    mask = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float v = P::round(acc[q]);  // the layer output is rounded first (autocast), then ReLU
+        const bool on = v > 0.f;
+        mask |= on ? (1u << q) : 0u;
+        P::set(k, q, on ? v : 0.f);
+    }
+    return k;
+}
+template <class P>
+__device__ __forceinline__ typename P::KB masked_kb(f32x16 &acc, uint32_t mask) {
+    typename P::KB k;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc[q] = ((mask >> q) & 1u) ? acc[q] : 0.f;
+        P::set(k, q, acc[q]);
+    }
+    return k;
+}
+__device__ __forceinline__ f32x16 splat(float v) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = v;
+    return a;
+}
+// bias along the ROWS of the tile (orientation 1: rows = features)
+__device__ __forceinline__ f32x16 bias_rows(const float *bias, int h) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = bias[rowmap(q, h)];
+    return a;
+}
+__device__ __forceinline__ float sum16(const f32x16 &a) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += a[q];
+    return s;
+}
+
+// ---------------------------------------------------------------- forward
+template <class P>
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t n, Weights w,
+                                                                     float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *bias = reinterpret_cast<float *>(lds + (size_t)B_FWD_COUNT * block_bytes<P>());
+    build_blocks<P>(lds, bias, w, B_FWD_COUNT);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), p = lane & 31, h = lane >> 5;
+    const uint32_t wave = blockIdx.x * kWavesPerWG + threadIdx.x / kWave, n_waves = gridDim.x * kWavesPerWG;
+    const uint32_t n_tiles = (n + 31) / 32;
+    // the lane offset is laundered through an empty asm so every use is a fresh LDS read: hipcc would otherwise
+    // hoist all (loop-invariant) operand blocks into registers and spill the accumulators
+    auto blk = [&](int b) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return P::load_block(lds + (size_t)b * block_bytes<P>(), l);
+    };
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const size_t row = (size_t)tile * 32 + p;
+        const bool valid = row < n;
+        const typename P::KB X = load_rows_kb<P>(x, row, valid, h);
+        typename P::KB H1[NTH], H2[NTH];
+        uint32_t m;
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = bias_rows(bias + 32 * t, h);
+            P::mma(acc, blk(B_W1 + t), X);
+            H1[t] = relu_kb<P>(acc, m);
+        }
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = bias_rows(bias + HID + 32 * t, h);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2 + t * NTH + tk), H1[tk]);
+            H2[t] = relu_kb<P>(acc, m);
+        }
+        f32x16 acc = bias_rows(bias + 2 * HID, h);
+#pragma unroll
+        for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W3 + tk), H2[tk]);
+        if (valid && h == 0) {  // rows 0..3 of the tile = the four outputs, held by lane-half 0 in registers 0..3
+            f32x4 o = {P::round(acc[0]), P::round(acc[1]), P::round(acc[2]), P::round(acc[3])};
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(out + row * DOUT));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward
+struct Grads {
+    float *dW1, *db1, *dW2, *db2, *dW3, *db3;
+};
+
+template <class P>
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x,
+                                                                      const float *__restrict__ dout, uint32_t n,
+                                                                      Weights w, float *__restrict__ dx, Grads g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
+    build_blocks<P>(lds, bias, w, B_ALL_COUNT);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), p = lane & 31, h = lane >> 5;
+    const uint32_t wave = blockIdx.x * kWavesPerWG + threadIdx.x / kWave, n_waves = gridDim.x * kWavesPerWG;
+    const uint32_t n_tiles = (n + 31) / 32;
+    // the lane offset is laundered through an empty asm so every use is a fresh LDS read: hipcc would otherwise
+    // hoist all (loop-invariant) operand blocks into registers and spill the accumulators
+    auto blk = [&](int b) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return P::load_block(lds + (size_t)b * block_bytes<P>(), l);
+    };
+
+    // weight-gradient tiles: lane = column (input-side feature), register q = row rowmap(q, h) (output-side feature)
+    f32x16 gW2[NTH][NTH], gW1[NTH], gW3[NTH];
+    float gb1[NTH], gb2[NTH], gb3 = 0.f;
+#pragma unroll
+    for (int a = 0; a < NTH; ++a) {
+        gW1[a] = splat(0.f); gW3[a] = splat(0.f); gb1[a] = 0.f; gb2[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NTH; ++b) gW2[a][b] = splat(0.f);
+    }
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const size_t row0 = (size_t)tile * 32, row = row0 + p;
+        const bool valid = row < n;
+        const typename P::KB X = load_rows_kb<P>(x, row, valid, h);
+        const typename P::KB dO = load_dout_kb<P>(dout, row, valid, h);
+
+        // ---- orientation 1 (lane = sample): recompute the activations and their ReLU masks
+        typename P::KB H1[NTH], H2[NTH];
+        uint32_t m1[NTH], m2[NTH];
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = bias_rows(bias + 32 * t, h);
+            P::mma(acc, blk(B_W1 + t), X);
+            H1[t] = relu_kb<P>(acc, m1[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = bias_rows(bias + HID + 32 * t, h);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2 + t * NTH + tk), H1[tk]);
+            H2[t] = relu_kb<P>(acc, m2[t]);
+        }
+        // ---- orientation 1: input-side gradients  dH2 = W3^T dO, dH1 = W2^T dH2, dX = W1^T dH1
+        typename P::KB dH2[NTH], dH1[NTH];
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = splat(0.f);
+            P::mma_lo(acc, blk(B_W3T + t), dO);
+            dH2[t] = masked_kb<P>(acc, m2[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2T + t * NTH + tk), dH2[tk]);
+            dH1[t] = masked_kb<P>(acc, m1[t]);
+        }
+        {
+            f32x16 acc = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W1T + tk), dH1[tk]);
+            if (valid) {  // register q = input feature rowmap(q, h): four runs of four features
+                float *dst = dx + row * DIN + 4 * h;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 o = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
+                }
+            }
+        }
+
+        // ---- orientation 2 (lane = feature, registers = the tile's 32 samples): operands of the weight gradients
+        // hidden-1 activations and their gradient
+        typename P::KB H1p[NTH], dH2p[NTH];
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = splat(bias[32 * t + p]);
+            P::mma(acc, X, blk(B_W1 + t));
+            uint32_t m;
+            H1p[t] = relu_kb<P>(acc, m);
+            m1[t] = m;  // from here on m1 holds the orientation-2 mask (orientation-1 masks are consumed)
+        }
+        // dO with lane = output index, values = samples (A operand of dW3); its sum over samples is db3
+        typename P::KB dOp;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const size_t r = row0 + rowmap(q, h);
+            const float v = (p < DOUT && r < n) ? dout[r * DOUT + p] : 0.f;
+            P::set(dOp, q, v);
+            gb3 += v;
+        }
+        // hidden-2 pre-activations (for the mask and for dW3), gradient wrt hidden-2
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = splat(bias[HID + 32 * t + p]);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, H1[tk], blk(B_W2 + t * NTH + tk));
+            uint32_t m;
+            const typename P::KB H2p = relu_kb<P>(acc, m);
+            P::mma(gW3[t], dOp, H2p);  // dW3[o][f] += sum_s dO[s][o] H2[s][f]
+            f32x16 d = splat(0.f);
+            P::mma_lo(d, dO, blk(B_W3T + t));
+            dH2p[t] = masked_kb<P>(d, m);
+            gb2[t] += sum16(d);
+        }
+        // dW2[i][j] += sum_s dH2[s][i] H1[s][j]
+#pragma unroll
+        for (int ti = 0; ti < NTH; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NTH; ++tj) P::mma(gW2[ti][tj], dH2p[ti], H1p[tj]);
+        // gradient wrt hidden-1 in orientation 2, then dW1[i][j] += sum_s dH1[s][i] X[s][j]
+        typename P::KB Xp;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const size_t r = row0 + rowmap(q, h);
+            P::set(Xp, q, r < n ? x[r * DIN + p] : 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 d = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) P::mma(d, dH2[tk], blk(B_W2T + t * NTH + tk));
+            const typename P::KB dH1p = masked_kb<P>(d, m1[t]);
+            gb1[t] += sum16(d);
+            P::mma(gW1[t], dH1p, Xp);
+        }
+    }
+
+    // ---- reduce the weight gradients across the workgroup in LDS, then one atomic per element per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);
+    constexpr int OFF_W1 = 0, OFF_B1 = OFF_W1 + HID * DIN, OFF_W2 = OFF_B1 + HID, OFF_B2 = OFF_W2 + HID * HID,
+                  OFF_W3 = OFF_B2 + HID, OFF_B3 = OFF_W3 + DOUT * HID, TOTAL = OFF_B3 + DOUT;
+    for (int e = threadIdx.x; e < TOTAL; e += blockDim.x) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = rowmap(q, h);
+#pragma unroll
+        for (int ti = 0; ti < NTH; ++ti) {
+            atomicAdd(&red[OFF_W1 + (32 * ti + r) * DIN + p], gW1[ti][q]);
+#pragma unroll
+            for (int tj = 0; tj < NTH; ++tj) atomicAdd(&red[OFF_W2 + (32 * ti + r) * HID + 32 * tj + p], gW2[ti][tj][q]);
+            if (r < DOUT) atomicAdd(&red[OFF_W3 + r * HID + 32 * ti + p], gW3[ti][q]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+        atomicAdd(&red[OFF_B1 + 32 * t + p], gb1[t]);
+        atomicAdd(&red[OFF_B2 + 32 * t + p], gb2[t]);
+    }
+    if (p < DOUT) atomicAdd(&red[OFF_B3 + p], gb3);
+    __syncthreads();
+    for (int e = threadIdx.x; e < TOTAL; e += blockDim.x) {
+        const float v = red[e];
+        float *dst = e < OFF_B1 ? g.dW1 + (e - OFF_W1)
+                   : e < OFF_W2 ? g.db1 + (e - OFF_B1)
+                   : e < OFF_B2 ? g.dW2 + (e - OFF_W2)
+                   : e < OFF_W3 ? g.db2 + (e - OFF_B2)
+                   : e < OFF_B3 ? g.dW3 + (e - OFF_W3)
+                                : g.db3 + (e - OFF_B3);
+        if (v != 0.f) unsafeAtomicAdd(dst, v);
+    }
+}
+
+template <class P> constexpr size_t lds_bytes(int n_blocks) {
+    return (size_t)n_blocks * block_bytes<P>() + (HID + HID + 32) * sizeof(float);
+}
+
+int grid_for(uint32_t n) {
+    const uint32_t tiles = (n + 31) / 32, wgs = (tiles + kWavesPerWG - 1) / kWavesPerWG;
+    const uint32_t cap = 256 * 2;  // persistent: two workgroups per CU
+    return (int)(wgs < cap ? (wgs ? wgs : 1) : cap);
+}
+
+bool dims_ok(uint32_t di, uint32_t dh, uint32_t dout, uint32_t layers) {
+    return di == DIN && dh == HID && dout == DOUT && layers == 3;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, uint32_t num_layers) {
+    return dims_ok(dim_in, dim_hidden, dim_out, num_layers) ? 1 : 0;
+}
+
+int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
+                     int half_mode, float *out, void *stream) {
+    if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    const Weights w{W1, b1, W2, b2, W3, b3};
+    if (half_mode)
+        hipLaunchKernelGGL(k_mlp_forward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
+                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, n, w, out);
+    else
+        hipLaunchKernelGGL(k_mlp_forward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
+                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, n, w, out);
+    return (int)hipGetLastError();
+}
+
+int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float *W1, const float *b1,
+                      const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, float *dW1, float *db1,
+                      float *dW2, float *db2, float *dW3, float *db3, void *stream) {
+    if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    const Weights w{W1, b1, W2, b2, W3, b3};
+    const Grads g{dW1, db1, dW2, db2, dW3, db3};
+    if (half_mode)
+        hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
+                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, g);
+    else
+        hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
+                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, g);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -33,7 +33,7 @@ def _timed(kind, launch, evals):
     e0.record()
     launch()
     e1.record()
-    PROFILE[kind].append((e0, e1))
+    PROFILE.setdefault(kind, []).append((e0, e1))
     PROFILE.setdefault(kind + "_evals", []).append(evals)
 
 

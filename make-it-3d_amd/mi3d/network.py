@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 import tinycudann as tcnn
 
-from . import grid_ops
+from . import grid_ops, mlp_ops
 from .renderer import NeRFRenderer, safe_normalize
 
 
@@ -48,20 +48,16 @@ class MLP(nn.Module):
             nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=bias)
             for l in range(num_layers)])
 
-    # hipBLASLt's heuristic picks a 16x16 macro-tile for the [rows,64] x [64,4] head GEMM (measured 1078 ms for
-    # 142 M rows on MI355X, profiles/bench_r01_c2_dense_stats_a.csv); padding the output width to 32 zero rows makes
-    # it pick the same kernel family as the hidden layers.  Only used when the fused MFMA MLP (csrc/field.hip) is off.
-    _PAD_OUT = 32
+    def fused_ok(self, x):
+        """The matrix-core kernel covers the shape network_tcnn.py:67 builds (32 -> 64 -> 64 -> 4, biased)."""
+        return (x.is_cuda and all(l.bias is not None for l in self.net)
+                and mlp_ops.supported(self.dim_in, self.dim_hidden, self.dim_out, self.num_layers))
 
     def forward(self, x):
-        for l, layer in enumerate(self.net):
-            if l == self.num_layers - 1 and layer.out_features < self._PAD_OUT and x.shape[0] >= (1 << 16):
-                pad = self._PAD_OUT - layer.out_features
-                w = torch.cat([layer.weight, layer.weight.new_zeros(pad, layer.in_features)], 0)
-                b = torch.cat([layer.bias, layer.bias.new_zeros(pad)], 0) if layer.bias is not None else None
-                x = F.linear(x, w, b)[:, :layer.out_features]
-            else:
-                x = layer(x)
+        if self.fused_ok(x):
+            return mlp_ops.fused_mlp(x, self.net)
+        for l, layer in enumerate(self.net):  # other shapes (e.g. BASELINE config 1's 8 -> 32 -> 4): library GEMMs
+            x = layer(x)
             if l != self.num_layers - 1:
                 x = F.relu(x, inplace=True)
         return x
