@@ -144,7 +144,8 @@ __device__ __forceinline__ bool quad_merge_runs(bool active, const CellKey &key,
 
 __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t n, const int32_t *count,
                                                             const float *__restrict__ dout, GridTable T,
-                                                            uint32_t merge_levels, float *__restrict__ grad_table) {
+                                                            uint32_t merge_levels, uint32_t level_mask,
+                                                            float *__restrict__ grad_table) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     if (count != nullptr) { const uint32_t c = (uint32_t)max(*count, 0); n = c < n ? c : n; }
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
             point_of(ps, base, p, q);
             const float *drow = dout + ((size_t)s * ps.P + p) * F + f;
             for (uint32_t l = wave; l < T.n_levels; l += kWaves) {
+                if (!((level_mask >> l) & 1u)) continue;
                 const GridLevel L = T.level[l];
                 const float d = valid ? drow[2 * l] : 0.f;
                 // a row whose two feature gradients are both zero (padding, masked samples) is skipped
@@ -208,8 +210,10 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
     static const int force = getenv("MI3D_SCATTER") ? atoi(getenv("MI3D_SCATTER")) : -1;  // profiling A/B only
     if (force >= 0) merge_levels = (uint32_t)force;
     if (merge_levels > T.n_levels) merge_levels = T.n_levels;
+    const char *lm = getenv("MI3D_SCATTER_LMASK");  // profiling only: restrict the scatter to a subset of levels
+    const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
-                       merge_levels, grad_params);
+                       merge_levels, level_mask, grad_params);
     return (int)hipGetLastError();
 }
 
