@@ -1,0 +1,96 @@
+"""CPU: the product's own scalar math (make-it-3d_amd/csrc/mi3d_common.h - the DDA step, Morton codes and hash-grid
+indexing the HIP kernels execute) compiled for the HOST and compared bit-for-bit with the oracle, so that index-exactness
+is established before a GPU is involved.  tests/host_math/host_math.cpp is the thin extern-C shim."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, make_rays, random_bitfield, sphere_bitfield
+
+HERE = os.path.join(ROOT, "tests", "host_math")
+
+
+@pytest.fixture(scope="module")
+def hm():
+    so = os.path.join(HERE, "libhostmath.so")
+    src = os.path.join(HERE, "host_math.cpp")
+    hdr = os.path.join(PKG, "csrc", "mi3d_common.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               "-I", os.path.join(PKG, "csrc"), src, "-o", so])
+    return C.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("C_,bound,kind,dt_gamma,max_steps,perturb", [
+    (1, 1.0, "ones", 0.0, 256, False), (1, 1.0, "sphere", 0.0, 512, True), (1, 1.0, "random", 1 / 128, 256, True),
+    (2, 2.0, "sphere", 0.0, 256, True), (3, 4.0, "random", 1 / 128, 128, False)])
+def test_march_bit_exact_with_oracle(hm, oracle, C_, bound, kind, dt_gamma, max_steps, perturb):
+    rng = np.random.default_rng(11)
+    N, H = 500, 128
+    o, d = make_rays(rng, N, bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb)
+    bits = {"ones": lambda: np.full(C_ * H ** 3 // 8, 255, np.uint8), "sphere": lambda: sphere_bitfield(oracle, C_, H, 0.45 * bound),
+            "random": lambda: random_bitfield(rng, C_, H)}[kind]()
+    noises = rng.uniform(0, 1, N).astype(np.float32) if perturb else None
+    xr, dr, lr, rr, cr = oracle.march_rays_train(o, d, bound, bits, C_, H, nears, fars, noises, align=-1,
+                                                 dt_gamma=dt_gamma, max_steps=max_steps, return_counter=True)
+    M = N * max_steps
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    rays, counter = np.zeros((N, 3), np.int32), np.zeros(2, np.int32)
+    nz = np.zeros(N, np.float32) if noises is None else noises
+    hm.hm_march_train(_p(o), _p(d), _p(bits), C.c_float(bound), C.c_float(dt_gamma), C.c_uint32(max_steps),
+                      C.c_uint32(N), C.c_uint32(C_), C.c_uint32(H), C.c_uint32(M), _p(nears), _p(fars), _p(xyzs),
+                      _p(dirs), _p(deltas), _p(rays), _p(counter), _p(nz))
+    assert np.array_equal(counter, cr)
+    # the oracle lays rays out in ray order too (sequential host loop): everything must agree bit for bit
+    assert np.array_equal(rays, rr)
+    m = int(counter[0])
+    assert np.array_equal(xyzs[:m].view(np.uint32), xr[:m].view(np.uint32))
+    assert np.array_equal(deltas[:m].view(np.uint32), lr[:m].view(np.uint32))
+    assert np.array_equal(dirs[:m].view(np.uint32), dr[:m].view(np.uint32))
+
+
+def test_morton_bit_exact_with_oracle(hm, oracle):
+    rng = np.random.default_rng(2)
+    co = rng.integers(0, 1024, (20000, 3)).astype(np.int32)
+    out = np.empty(20000, np.int32)
+    hm.hm_morton(_p(co), C.c_uint32(20000), _p(out))
+    assert np.array_equal(out, oracle.morton3D(co))
+    back = np.empty((20000, 3), np.int32)
+    hm.hm_morton_invert(_p(out), C.c_uint32(20000), _p(back))
+    assert np.array_equal(back, co)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(n_levels=4, per_level_scale=128 ** (1 / 3)),
+                                dict(n_levels=6, log2_hashmap_size=12, base_resolution=4, per_level_scale=1.7)])
+def test_grid_corner_indices_bit_exact_with_oracle(hm, oracle, kw):
+    import tinycudann as tcnn
+    cfg = oracle.GridConfig(**kw)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    x[0] = 0.0; x[1] = 1.0; x[2] = [1.0, 0.0, 0.999999]
+    idx_ref, w_ref = oracle.hashgrid_indices(x, cfg)
+    total, offs, res, scl = tcnn.grid_levels(cfg.n_levels, cfg.base_resolution, cfg.per_level_scale,
+                                             cfg.log2_hashmap_size)
+    assert total == cfg.n_entries
+    for l in range(cfg.n_levels):
+        size = int(offs[l + 1] - offs[l])
+        stride, dims = 1, 0
+        while dims < 3 and stride <= size:
+            stride *= int(res[l]); dims += 1
+        hashed = 1 if size < stride else 0
+        idx, w = np.empty((3000, 8), np.uint32), np.empty((3000, 8), np.float32)
+        hm.hm_grid_corners(_p(x), C.c_uint32(3000), C.c_float(float(scl[l])), C.c_uint32(int(res[l])),
+                           C.c_uint32(int(offs[l])), C.c_uint32(size), C.c_uint32(hashed), C.c_uint32(dims), _p(idx),
+                           _p(w))
+        ref_local = idx_ref[:, l, :] - (0 if idx_ref[:, l, :].max() < size else offs[l])
+        assert np.array_equal(idx, ref_local.astype(np.uint32)), l
+        assert np.array_equal(w.view(np.uint32), w_ref[:, l, :].view(np.uint32)), l
