@@ -22,6 +22,7 @@
 #ifndef MI3D_H
 #define MI3D_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -134,6 +135,19 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
                              uint32_t log2_hashmap_size, float step, float *grad_params, void *stream);
 
+/* The same scatter without global atomics on the big (hashed) levels: every corner contribution is appended as a
+ * 12-byte record to the region of its 64-KB gradient bin, then each bin is accumulated in LDS (see hashgrid.hip).
+ * `dout_planes` is level-major [n_levels][n*P][2] (what mi3d_mlp_backward writes with dx_planes != 0).
+ * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
+ * it; with workspace == NULL or too small for even 64 samples everything falls back to the atomic path.
+ * mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice (0: nothing to bin). */
+size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, uint32_t n_levels, uint32_t base_resolution,
+                                          float per_level_scale, uint32_t log2_hashmap_size);
+int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                             uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
+                             uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
+                             void *workspace, size_t workspace_bytes, float *grad_params, void *stream);
+
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 
 /* network_tcnn.py:13-32: y = W3 relu(W2 relu(W1 x + b1) + b2) + b3, torch nn.Linear layout (W_l is [out_l, in_l]
@@ -147,12 +161,14 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
 int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream);
-/* Backward of the above for upstream gradient dout [n, dim_out]: writes dx [n, dim_in] and ACCUMULATES the weight
- * and bias gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed. */
+/* Backward of the above for upstream gradient dout [n, dim_out]: writes dx and ACCUMULATES the weight and bias
+ * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
+ * dx_planes == 0: dx is [n, dim_in] rows; dx_planes != 0: dx is level-major planes [dim_in/2][n][2] (feature pair
+ * (2l, 2l+1) of row r at dx[(l*n + r)*2]), the layout mi3d_grid_scatter_binned consumes. */
 int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, float *dW1, float *db1,
-                      float *dW2, float *db2, float *dW3, float *db3, void *stream);
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
+                      float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream);
 
 #ifdef __cplusplus
 }

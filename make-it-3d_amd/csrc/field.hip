@@ -36,6 +36,7 @@ constexpr int NTH = HID / 32;  // 32-wide tiles across the hidden width
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -278,7 +279,8 @@ struct Grads {
 template <class P>
 __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x,
                                                                       const float *__restrict__ dout, uint32_t n,
-                                                                      Weights w, float *__restrict__ dx, Grads g) {
+                                                                      Weights w, float *__restrict__ dx, int dx_planes,
+                                                                      Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_ALL_COUNT);
@@ -345,12 +347,22 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
             f32x16 acc = splat(0.f);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W1T + tk), dH1[tk]);
-            if (valid) {  // register q = input feature rowmap(q, h): four runs of four features
+            if (valid && !dx_planes) {  // register q = input feature rowmap(q, h): four runs of four features
                 float *dst = dx + row * DIN + 4 * h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     f32x4 o = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
                     __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
+                }
+            } else if (valid) {
+                // level-major planes [DIN/2][n][2] (what the binned scatter reads): features (2l, 2l+1) of this row
+                // are one 8-byte store; lane-half h owns levels 4c + 2h and 4c + 2h + 1, 32 consecutive rows per store
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x2 a = {acc[4 * c], acc[4 * c + 1]}, b = {acc[4 * c + 2], acc[4 * c + 3]};
+                    const size_t lvl = 4 * c + 2 * h;
+                    __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * n + row) * 2));
+                    __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * n + row) * 2));
                 }
             }
         }
@@ -488,18 +500,18 @@ int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b
 
 int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, float *dW1, float *db1,
-                      float *dW2, float *db2, float *dW3, float *db3, void *stream) {
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
+                      float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream) {
     if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, g);
+                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, dx_planes, g);
     else
         hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, g);
+                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, dx_planes, g);
     return (int)hipGetLastError();
 }
 

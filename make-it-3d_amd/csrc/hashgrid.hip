@@ -145,7 +145,13 @@ __device__ __forceinline__ bool quad_merge_runs(bool active, const CellKey &key,
 __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t n, const int32_t *count,
                                                             const float *__restrict__ dout, GridTable T,
                                                             uint32_t merge_levels, uint32_t level_mask,
+                                                            uint32_t plane_rows, uint32_t n_rep, size_t rep_stride,
                                                             float *__restrict__ grad_table) {
+    // n_rep > 1: grad_table is a stack of n_rep private copies (rep_stride floats apart) of the table prefix the
+    // selected levels live in; workgroup b adds into copy b % n_rep.  The few lines of a coarse level are hit by every
+    // workgroup, and atomics on ONE line serialise at the memory side (~0.3 us each, profiles/scatter_levels_r01.json);
+    // spreading them over copies removes the serialisation, k_replica_reduce sums the copies afterwards.
+    grad_table += (size_t)(blockIdx.x % n_rep) * rep_stride;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     if (count != nullptr) { const uint32_t c = (uint32_t)max(*count, 0); n = c < n ? c : n; }
@@ -163,11 +169,13 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
         for (uint32_t p = 0; p < ps.P; ++p) {
             float q[3];
             point_of(ps, base, p, q);
-            const float *drow = dout + ((size_t)s * ps.P + p) * F + f;
+            const size_t row = (size_t)s * ps.P + p;
+            const float *drow = dout + row * F + f;
             for (uint32_t l = wave; l < T.n_levels; l += kWaves) {
                 if (!((level_mask >> l) & 1u)) continue;
                 const GridLevel L = T.level[l];
-                const float d = valid ? drow[2 * l] : 0.f;
+                // dout is either [rows, 2L] or (plane_rows != 0) level-major planes [L][plane_rows][2]
+                const float d = !valid ? 0.f : plane_rows ? dout[((size_t)l * plane_rows + row) * 2 + f] : drow[2 * l];
                 // a row whose two feature gradients are both zero (padding, masked samples) is skipped
                 const float d_other = __shfl_xor(d, 1, 64);  // the quad's other feature (unconditional: all lanes)
                 const bool has = valid && (d != 0.f || d_other != 0.f);
@@ -206,14 +214,16 @@ PointSet make_points(const float *x, const float *x2, const float *offsets_host,
 }
 
 int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const float *dout, const GridTable &T,
-                   uint32_t merge_levels, float *grad_params, hipStream_t st) {
+                   uint32_t merge_levels, float *grad_params, hipStream_t st, uint32_t level_mask = 0xFFFFFFFFu,
+                   uint32_t plane_rows = 0, uint32_t n_rep = 1, size_t rep_stride = 0) {
     static const int force = getenv("MI3D_SCATTER") ? atoi(getenv("MI3D_SCATTER")) : -1;  // profiling A/B only
     if (force >= 0) merge_levels = (uint32_t)force;
     if (merge_levels > T.n_levels) merge_levels = T.n_levels;
     const char *lm = getenv("MI3D_SCATTER_LMASK");  // profiling only: restrict the scatter to a subset of levels
-    const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xFFFFFFFFu;
+    if (lm) level_mask &= (uint32_t)strtoul(lm, nullptr, 0);
+    if ((level_mask & ((1ull << T.n_levels) - 1)) == 0) return 0;
     hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
-                       merge_levels, level_mask, grad_params);
+                       merge_levels, level_mask, plane_rows, n_rep, rep_stride, grad_params);
     return (int)hipGetLastError();
 }
 
@@ -223,6 +233,253 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
     for (uint32_t l = 0; l < T.n_levels; ++l)
         if (1.0f / (float)T.level[l].res >= 1.05f * step01) m = l + 1;
     return m;
+}
+
+
+// ================================================================ binned scatter (no global atomics on the big levels)
+//
+// The chip retires ~21 G atomic requests/s no matter what (profiles/atomics_r01.txt, atomics3_r01.txt), and on the
+// hashed levels nothing merges: 8 corners of every (sample, point) land in 4 random 64-byte blocks.  Plain stores and
+// LDS atomics are an order of magnitude cheaper, so the big levels go through memory instead:
+//   pass 1 (k_bin_emit)   every corner contribution becomes a 12-byte record {entry, g0, g1} appended to the region
+//                         of its BIN (8192 consecutive entries = 64 KB of gradient) - one private region per
+//                         (wave, bin), so appends are a wave-private LDS counter and a plain store, no atomics;
+//                         the arena is wave-major ([wave][bin][cap]) so the 64 regions a wave is filling at any
+//                         moment (one level's bins) sit in one 4 MB span: two TLB pages instead of 64;
+//   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS
+//                         (ds_add_f32), then adds the 64 KB tile to the gradient table.
+// Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
+constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
+constexpr uint32_t kEmitWavesMax = 2048, kReduceSplit = 4;  // 2048 waves: the lines being appended to fit the L2s
+
+struct __attribute__((packed, aligned(4))) BinRecord {
+    uint32_t entry;  // level-local entry index
+    float g0, g1;
+};
+
+struct BinPlan {
+    uint32_t level_bin0[MI3D_MAX_LEVELS];  // first bin of each binned level
+    uint32_t binned_mask, n_bins, cap, n_waves;
+    uint32_t debug;  // profiling only (MI3D_BIN_DEBUG): 1 = reduce skips the LDS adds, 2 = emit skips the record stores
+};
+
+inline bool level_is_binned(const GridLevel &L) { return L.size >= 8 * kBinEntries && L.size % kBinEntries == 0; }
+
+inline BinPlan make_bin_plan(const GridTable &T) {
+    BinPlan p{};
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        p.level_bin0[l] = p.n_bins;
+        if (level_is_binned(T.level[l])) { p.binned_mask |= 1u << l; p.n_bins += T.level[l].size / kBinEntries; }
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
+                                                             const float *__restrict__ dplanes, uint32_t plane_rows,
+                                                             GridTable T, BinPlan plan, uint32_t merge_levels,
+                                                             BinRecord *__restrict__ arena,
+                                                             uint32_t *__restrict__ counts,
+                                                             float *__restrict__ level_max,
+                                                             float *__restrict__ grad_table) {
+    extern __shared__ uint32_t fill_all[];  // [kWaves][n_bins] records appended so far by this wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
+    uint32_t *fill = fill_all + wave_in_wg * plan.n_bins;
+    for (uint32_t b = lane; b < plan.n_bins; b += kWave) fill[b] = 0;
+    if (gw >= plan.n_waves) return;
+    const size_t region_stride = (size_t)plan.cap;
+    float vmax[MI3D_MAX_LEVELS];  // largest |record value| this lane emitted, per level (fixes the reduce's scale)
+#pragma unroll
+    for (int l = 0; l < MI3D_MAX_LEVELS; ++l) vmax[l] = 0.f;
+
+    for (uint32_t s0 = s_begin + gw * kWave; s0 < s_end; s0 += plan.n_waves * kWave) {
+        const uint32_t s = s0 + lane;
+        const bool valid = s < s_end;
+        float base[2][3];
+        load_bases(ps, s, valid, base);
+#pragma unroll
+        for (uint32_t l = 0; l < (uint32_t)MI3D_MAX_LEVELS; ++l) {
+            if (l >= T.n_levels || !((plan.binned_mask >> l) & 1u)) continue;
+            const GridLevel L = T.level[l];
+            const uint32_t bin0 = plan.level_bin0[l];
+            float lmax = 0.f;
+            const float2 *plane = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows;
+            // the gradient pairs are fetched three points ahead of their use (the loop is latency-bound otherwise)
+            const float2 zero2 = make_float2(0.f, 0.f);
+            const float2 *prow = plane + (size_t)s * ps.P;
+            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[1] : zero2,
+                   d2 = (valid && 2 < ps.P) ? prow[2] : zero2;
+            for (uint32_t p = 0; p < ps.P; ++p) {
+                const float2 d = d0;
+                d0 = d1; d1 = d2;
+                d2 = (valid && p + 3 < ps.P) ? prow[p + 3] : zero2;
+                const bool has = valid && (d.x != 0.f || d.y != 0.f);
+                if (!__any(has)) continue;
+                float q[3];
+                point_of(ps, base, p, q);
+                uint32_t cx, cy, cz;
+                float fx, fy, fz;
+                grid_cell(q[0], L.scale, cx, fx);
+                grid_cell(q[1], L.scale, cy, fy);
+                grid_cell(q[2], L.scale, cz, fz);
+                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
+                const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[2 * k] = wk[k] * d.x; v[2 * k + 1] = wk[k] * d.y; }
+                bool owner = has;
+                if (l < merge_levels) owner = wave_merge_runs<16>(has, CellKey{cx, cy, cz}, v, lane);
+                if (owner) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) {
+                        const uint32_t e = grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2));
+                        const uint32_t b = bin0 + (e >> kBinShift);
+                        const uint32_t slot = atomicAdd(&fill[b], 1u);  // wave-private LDS counter
+                        lmax = fmaxf(lmax, fmaxf(fabsf(v[2 * k]), fabsf(v[2 * k + 1])));
+                        if (plan.debug & 2u) continue;
+                        if (slot < plan.cap) {
+                            BinRecord r{e, v[2 * k], v[2 * k + 1]};
+                            arena[((size_t)gw * plan.n_bins + b) * region_stride + slot] = r;
+                        } else {  // region full (cannot happen with the sizing below unless the hash is adversarial)
+                            float *dst = grad_table + ((size_t)L.offset + e) * 2;
+                            unsafeAtomicAdd(dst, v[2 * k]);
+                            unsafeAtomicAdd(dst + 1, v[2 * k + 1]);
+                        }
+                    }
+                }
+            }
+            vmax[l] = fmaxf(vmax[l], lmax);
+        }
+    }
+    for (uint32_t b = lane; b < plan.n_bins; b += kWave) {
+        const uint32_t c = fill[b];
+        counts[(size_t)gw * plan.n_bins + b] = c < plan.cap ? c : plan.cap;
+    }
+#pragma unroll
+    for (int l = 0; l < MI3D_MAX_LEVELS; ++l) {
+        float m = vmax[l];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) level_max[(size_t)gw * MI3D_MAX_LEVELS + l] = m;
+    }
+}
+
+constexpr int kReduceWaves = 16;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
+
+// LDS fp32 atomic adds retire 0.38 lanes/clk/CU on gfx950, 64-bit integer ones 5.3 (tools/lds_atomics_bench.hip,
+// profiles/lds_atomics_r01.txt), so the bin is accumulated in 64-bit FIXED POINT: every record value is scaled by a
+// power of two 2^k chosen from the largest |value| any wave emitted for the level (|v| 2^k < 2^38, so 2^24 records
+// cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is exact; what is dropped is whatever
+// lies more than 38 binary digits below the level's largest contribution - far below what fp32 running sums (24
+// digits) or the reference's fp16 autocast gradients resolve.
+__global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRecord *__restrict__ arena,
+                                                                     const uint32_t *__restrict__ counts,
+                                                                     const float *__restrict__ level_max, GridTable T,
+                                                                     BinPlan plan, float *__restrict__ grad_table) {
+    extern __shared__ unsigned long long acc[];  // [kBinEntries * 2]
+    __shared__ float wg_max[kReduceWaves];
+    const uint32_t b = blockIdx.x / kReduceSplit, split = blockIdx.x % kReduceSplit;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave_in_wg = threadIdx.x / kWave;
+    uint32_t lvl = 0;  // which level does this bin belong to?  (uniform scan of at most 16 entries)
+    for (uint32_t l = 0; l < T.n_levels; ++l)
+        if (((plan.binned_mask >> l) & 1u) && plan.level_bin0[l] <= b) lvl = l;
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) acc[i] = 0ull;
+    float m = 0.f;
+    for (uint32_t r = threadIdx.x; r < plan.n_waves; r += blockDim.x) m = fmaxf(m, level_max[(size_t)r * MI3D_MAX_LEVELS + lvl]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) wg_max[wave_in_wg] = m;
+    __syncthreads();
+    m = 0.f;
+    for (int w = 0; w < kReduceWaves; ++w) m = fmaxf(m, wg_max[w]);
+    if (!(m > 0.f)) return;  // nothing but zeros was emitted for this level (uniform across the workgroup)
+    int e;
+    (void)frexpf(m, &e);  // m < 2^e
+    int k = 38 - e;
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    const float scale = ldexpf(1.0f, k);
+    const double unscale = ldexp(1.0, -k);
+
+    bool any = false;
+    constexpr uint32_t U = 4;  // records in flight per lane
+    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < plan.n_waves; r += kReduceSplit * kReduceWaves) {
+        const uint32_t cnt = counts[(size_t)r * plan.n_bins + b];
+        const BinRecord *src = arena + ((size_t)r * plan.n_bins + b) * plan.cap;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
+            BinRecord rec[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u * kWave + lane;
+                rec[u] = i < cnt ? src[i] : BinRecord{0u, 0.f, 0.f};
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                if (plan.debug & 1u) {
+                    if (rec[u].g0 == 12345.678f) acc[lane] = 1ull;
+                } else if (i0 + u * kWave + lane < cnt) {
+                    const uint32_t local = (rec[u].entry & (kBinEntries - 1)) * 2;
+                    atomicAdd(&acc[local], (unsigned long long)__float2ll_rn(rec[u].g0 * scale));
+                    atomicAdd(&acc[local + 1], (unsigned long long)__float2ll_rn(rec[u].g1 * scale));
+                }
+            }
+        }
+        any |= cnt != 0;
+    }
+    if (!__syncthreads_or((int)any)) return;
+    float *dst = grad_table + ((size_t)T.level[lvl].offset + (size_t)(b - plan.level_bin0[lvl]) * kBinEntries) * 2;
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) {
+        const long long a = (long long)acc[i];
+        if (a != 0) unsafeAtomicAdd(dst + i, (float)((double)a * unscale));
+    }
+}
+
+// grad[i] += sum over the n_rep private copies
+__global__ void k_replica_reduce(const float *__restrict__ rep, uint32_t n_rep, size_t rep_stride, uint32_t count,
+                                 float *__restrict__ grad_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (uint32_t r = 0; r < n_rep; ++r) s += rep[(size_t)r * rep_stride + i];
+    if (s != 0.f) grad_table[i] += s;
+}
+
+constexpr uint32_t kReplicas = 64;
+// entries of the table prefix made of the levels that are NOT binned (0 when those levels are not a prefix)
+inline uint32_t unbinned_prefix_entries(const GridTable &T, const BinPlan &plan) {
+    uint32_t l = 0, entries = 0;
+    while (l < T.n_levels && !((plan.binned_mask >> l) & 1u)) { entries = T.level[l].offset + T.level[l].size; ++l; }
+    for (uint32_t k = l; k < T.n_levels; ++k)
+        if (!((plan.binned_mask >> k) & 1u)) return 0;
+    return entries;
+}
+
+// records one (bin, wave) region must hold for a slice of n_slice samples, with 25 % head room over the uniform share
+inline uint32_t bin_region_cap(uint64_t n_slice, uint32_t P, uint32_t bins_per_level, uint32_t n_waves) {
+    const uint64_t per = (n_slice * P * 8 + (uint64_t)bins_per_level * n_waves - 1) / ((uint64_t)bins_per_level * n_waves);
+    return (uint32_t)(per + per / 4 + 64);
+}
+inline uint32_t emit_waves_for(uint64_t n) {
+    const uint64_t w = (n + kWave - 1) / kWave;
+    static const uint32_t cap_waves = getenv("MI3D_BIN_WAVES") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES")) : kEmitWavesMax;
+    uint32_t nw = (uint32_t)(w < cap_waves ? w : cap_waves);
+    nw = (nw + kWaves - 1) / kWaves * kWaves;
+    return nw ? nw : kWaves;
+}
+inline uint32_t min_bins_per_level(const GridTable &T, const BinPlan &plan) {
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t l = 0; l < T.n_levels; ++l)
+        if ((plan.binned_mask >> l) & 1u) { const uint32_t b = T.level[l].size / kBinEntries; m = b < m ? b : m; }
+    return m;
+}
+inline size_t bin_workspace_bytes(const BinPlan &plan, uint32_t cap, uint32_t n_waves) {
+    return (size_t)plan.n_bins * n_waves * ((size_t)cap * sizeof(BinRecord) + sizeof(uint32_t)) +
+           (size_t)n_waves * MI3D_MAX_LEVELS * sizeof(float);
+}
+inline size_t replica_bytes(const GridTable &T, const BinPlan &plan) {
+    return (size_t)kReplicas * unbinned_prefix_entries(T, plan) * 2 * sizeof(float);
 }
 
 }  // namespace
@@ -299,5 +556,91 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     return launch_scatter(ps, n, count, dout, T, default_merge_levels(T, step01), grad_params, as_stream(stream));
 }
+
+size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, uint32_t n_levels, uint32_t base_resolution,
+                                          float per_level_scale, uint32_t log2_hashmap_size) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || n == 0) return 0;
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    const BinPlan plan = make_bin_plan(T);
+    if (plan.n_bins == 0) return 0;
+    const uint32_t nw = emit_waves_for(n);
+    return bin_workspace_bytes(plan, bin_region_cap(n, P, min_bins_per_level(T, plan), nw), nw) + replica_bytes(T, plan);
+}
+
+int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                             uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
+                             uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
+                             void *workspace, size_t workspace_bytes, float *grad_params, void *stream) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
+        (P0 < P && x2 == nullptr))
+        return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
+    const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
+    const uint32_t merge_levels = default_merge_levels(T, step01);
+    BinPlan plan = make_bin_plan(T);
+    const uint32_t plane_rows = n * P;
+
+    // the tail of the workspace holds the private copies of the unbinned (dense) levels
+    const size_t rep_bytes = plan.n_bins ? replica_bytes(T, plan) : 0;
+    float *rep = nullptr;
+    if (workspace != nullptr && rep_bytes != 0 && workspace_bytes > rep_bytes) {
+        workspace_bytes -= rep_bytes;
+        rep = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + workspace_bytes);
+    }
+    // choose the slice: the largest sample count whose record arena fits the workspace
+    plan.n_waves = emit_waves_for(n);
+    const uint32_t bpl = plan.n_bins ? min_bins_per_level(T, plan) : 1;
+    uint64_t n_slice = n;
+    if (plan.n_bins) {
+        while (n_slice > kWave && bin_workspace_bytes(plan, bin_region_cap(n_slice, P, bpl, plan.n_waves), plan.n_waves) >
+                                      workspace_bytes)
+            n_slice = (n_slice + 1) / 2;
+        if (workspace == nullptr ||
+            bin_workspace_bytes(plan, bin_region_cap(n_slice, P, bpl, plan.n_waves), plan.n_waves) > workspace_bytes)
+            plan.n_bins = 0;  // no usable workspace: everything goes through the atomic path
+    }
+    const uint32_t atomic_mask = plan.n_bins ? ~plan.binned_mask : 0xFFFFFFFFu;
+    int err;
+    if (plan.n_bins && rep != nullptr) {
+        const uint32_t prefix = unbinned_prefix_entries(T, plan);
+        (void)hipMemsetAsync(rep, 0, rep_bytes, st);
+        err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, rep, st, atomic_mask, plane_rows, kReplicas,
+                             (size_t)prefix * 2);
+        hipLaunchKernelGGL(k_replica_reduce, dim3((prefix * 2 + 255) / 256), dim3(256), 0, st, rep, kReplicas,
+                           (size_t)prefix * 2, prefix * 2, grad_params);
+    } else {
+        err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, grad_params, st, atomic_mask, plane_rows);
+    }
+    if (err != 0 || plan.n_bins == 0) return err;
+
+    plan.cap = bin_region_cap(n_slice, P, bpl, plan.n_waves);
+    plan.debug = getenv("MI3D_BIN_DEBUG") ? (uint32_t)atoi(getenv("MI3D_BIN_DEBUG")) : 0u;
+    BinRecord *arena = reinterpret_cast<BinRecord *>(workspace);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(workspace) +
+                                                    (size_t)plan.n_bins * plan.n_waves * plan.cap * sizeof(BinRecord));
+    float *level_max = reinterpret_cast<float *>(counts + (size_t)plan.n_bins * plan.n_waves);
+    const size_t lds = (size_t)kWaves * plan.n_bins * sizeof(uint32_t);
+    const size_t lds_reduce = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_reduce);
+        attr_set = true;
+    }
+    for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
+        const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
+        hipLaunchKernelGGL(k_bin_emit, dim3(plan.n_waves / kWaves), dim3(kWave * kWaves), lds, st, ps, (uint32_t)s0, s1,
+                           dout_planes, plane_rows, T, plan, merge_levels, arena, counts, level_max, grad_params);
+        hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
+                           counts, level_max, T, plan, grad_params);
+    }
+    return (int)hipGetLastError();
+}
+
 
 }  // extern "C"

@@ -38,10 +38,11 @@ _SIGNATURES = {
     # Part 3 ------------------------------------------------------------------------------------------
     "mi3d_grid_encode_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, vp, vp],
     "mi3d_grid_scatter_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
+    "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, C.c_size_t, vp, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],
     "mi3d_mlp_forward": [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
-    "mi3d_mlp_backward": [vp, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_mlp_backward": [vp, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp],
 }
 
 
@@ -65,6 +66,8 @@ def lib():
         _lib.mi3d_last_error_string.argtypes = [C.c_int]
         _lib.mi3d_hashgrid_levels.restype = u32
         _lib.mi3d_hashgrid_levels.argtypes = [u32, u32, f32, u32, vp, vp, vp]
+        _lib.mi3d_grid_scatter_binned_workspace.restype = C.c_size_t
+        _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, u32, u32, f32, u32]
     return _lib
 
 

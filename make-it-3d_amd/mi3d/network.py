@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 import tinycudann as tcnn
 
-from . import grid_ops, mlp_ops
+from . import field_ops, grid_ops, mlp_ops
 from .renderer import NeRFRenderer, safe_normalize
 
 
@@ -108,7 +108,11 @@ class NeRFNetwork(NeRFRenderer):
     def _stencil_sigma(self, x, offsets, x2=None, P0=None, step=0.0):
         """sigma at clamp(base + offsets[p]) for every sample: [n, P]; plus albedo of point 0."""
         n, P = x.shape[0], offsets.shape[0]
-        h = self.sigma_net(self._encode(x, offsets, x2, P0, step)).view(n, P, 4)
+        if self.sigma_net.fused_ok(x) and self.encoder.cfg["n_levels"] * 2 == self.sigma_net.dim_in:
+            h = field_ops.field_stencil(self.encoder.params, self.sigma_net.net, x, offsets, self.encoder.cfg,
+                                        float(self.bound), x2, P0, step).view(n, P, 4)
+        else:
+            h = self.sigma_net(self._encode(x, offsets, x2, P0, step)).view(n, P, 4)
         offs = torch.from_numpy(offsets).to(x.device)
         base = x.unsqueeze(1).expand(n, P, 3)
         if x2 is not None:

@@ -119,3 +119,73 @@ def test_count_caps_rows_without_host_sync(cuda, oracle):
     p2 = grid_ops.encode_points(params, T(x[:keep], cuda), offs, kcfg)
     p2.sum().backward()
     assert torch.allclose(g_part, params.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("workspace", ["auto", "tiny", "none"])
+@pytest.mark.parametrize("second", [False, True])
+def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace):
+    """mi3d_grid_scatter_binned (records + LDS accumulation on the hashed levels, merged atomics on the dense ones) ==
+    sum of the oracle's per-point backward passes; 'tiny' forces several slices, 'none' the all-atomic fallback."""
+    from mi3d import field_ops, grid_ops
+    rng = np.random.default_rng(14)
+    bound = 1.0
+    cfg = oracle.GridConfig(bound=bound)
+    kcfg = dict(n_levels=cfg.n_levels, base_resolution=cfg.base_resolution, per_level_scale=cfg.per_level_scale,
+                log2_hashmap_size=cfg.log2_hashmap_size)
+    n = 3000
+    x = _ray_like_points(rng, n, bound)
+    x[:8] = bound
+    x2 = (x + rng.normal(size=x.shape).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=second)
+    P = offs.shape[0]
+    dout = rng.normal(size=(n, P, 16, 2)).astype(np.float32)
+    dout[100:140] = 0
+    dout[:, 2, 2] = 0
+    planes = np.ascontiguousarray(dout.reshape(n * P, 16, 2).transpose(1, 0, 2))  # [L][rows][2]
+    full = None
+    ws = {"auto": None, "none": 0}.get(workspace, "tiny")
+    if ws == "tiny":  # room for about a third of the samples per slice
+        import ctypes
+        from mi3d import _lib
+        need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 16, 16, ctypes.c_float(cfg.per_level_scale), 19)
+        ws = int(need)
+    g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda) if second else None, offs, P0, bound, T(planes, cuda), kcfg,
+                                 0.0034, cfg.n_params, workspace_bytes=ws).cpu().numpy()
+    ref = np.zeros(cfg.n_params, np.float64)
+    for p, pts in enumerate(_points(x, x2, offs, P0, bound)):
+        h01 = ((pts + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+        ref += oracle.hashgrid_backward(h01, dout[:, p].reshape(n, 32), cfg)
+    scale = np.abs(ref).max()
+    assert np.abs(g - ref).max() <= 2e-5 * scale + 1e-6
+    assert np.mean((g != 0) != (ref != 0)) < 1e-6
+
+
+def test_field_stencil_node_equals_layer_composition(cuda, oracle):
+    """The fused autograd node (encode + MLP, binned scatter) against the per-layer composition on the same inputs."""
+    from mi3d import field_ops, grid_ops, mlp_ops
+    from mi3d.network import MLP
+    rng = np.random.default_rng(15)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=16, base_resolution=16, per_level_scale=cfg.per_level_scale, log2_hashmap_size=19)
+    n = 2000
+    x = T(_ray_like_points(rng, n, 1.0), cuda)
+    x2 = x + torch.randn_like(x) * 0.01
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    torch.manual_seed(0)
+    mlp = MLP(32, 4, 64, 3).to(cuda)
+    table = torch.empty(cfg.n_params, device=cuda).uniform_(-0.5, 0.5)
+    g = torch.randn(n * offs.shape[0], 4, device=cuda)
+    outs = []
+    for fused in (True, False):
+        params = table.clone().requires_grad_(True)
+        mlp.zero_grad()
+        if fused:
+            h = field_ops.field_stencil(params, mlp.net, x, offs, kcfg, 1.0, x2, P0, step=0.0034, half_mode=False)
+        else:
+            h = mlp_ops.fused_mlp(grid_ops.encode_points(params, x, offs, kcfg, 1.0, x2, P0, step=0.0034), mlp.net,
+                                  half_mode=False)
+        h.backward(g)
+        outs.append([h.detach().clone(), params.grad.clone()] + [p.grad.clone() for p in mlp.parameters()])
+    for a, b in zip(*outs):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale
