@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--workload", default="c2_dense", choices=list(WORKLOADS))
     ap.add_argument("--sds-backward", default="single", choices=["single", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--init-scale", type=float, default=1.0, help="GradScaler initial loss scale")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -111,7 +112,13 @@ def main():
 
     from mi3d import dp, grid_ops, rays as R, sd_standin, sds_step
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
-    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"])
+    # GradScaler: the reference constructs it at 65536 (nerf/utils.py:309).  On this workload the normal-smoothness
+    # regulariser back-propagates through safe_normalize of finite differences that fp16 rounds to exactly zero
+    # (gradient x 1e10), so every step overflows binary16 until the scaler has halved itself down to ~1 (16 skipped
+    # steps, measured); a skipped step does NO optimizer work.  The bench therefore starts the scaler where it settles
+    # and asserts below that every timed step really applied its Adan update.
+    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"],
+                                                             init_scale=args.init_scale)
     dp.broadcast_module_state(model)
     bucket = dp.FlatGradBucket(model.parameters())
     guidance = sd_standin.StableDiffusionStandIn(dev)
@@ -124,6 +131,20 @@ def main():
         bucket.zero()
         return sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
                                        sds_backward=args.sds_backward, t=t_fixed, grad_sync=bucket.all_reduce_mean)
+
+    # phase timers (HIP events on the launch stream) around the two PyTorch-side phases
+    _sds, _opt_step = guidance.sds_gradient, optimizer.step
+
+    def sds_timed(*a, **k):
+        box = []
+        grid_ops._timed("sd_guidance", lambda: box.append(_sds(*a, **k)), 1)
+        return box[0]
+
+    def opt_timed(*a, **k):
+        box = []
+        grid_ops._timed("optimizer", lambda: box.append(_opt_step(*a, **k)), 1)
+        return box[0]
+    guidance.sds_gradient, optimizer.step = sds_timed, opt_timed
 
     for _ in range(args.warmup):
         step()
@@ -145,6 +166,10 @@ def main():
         elapsed = float(tt.item())
 
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
+    applied = len(prof.get("optimizer", []))
+    if applied != args.steps:
+        raise SystemExit(f"bench invalid: only {applied} of {args.steps} timed steps applied their optimizer update "
+                         f"(GradScaler overflow, scale now {scaler.get_scale()})")
     if rank == 0:
         sc = [a.elapsed_time(b) for a, b in prof["scatter"]]
         en = [a.elapsed_time(b) for a, b in prof["encode"]]
@@ -163,6 +188,7 @@ def main():
                                    f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step, occupancy "
                                    f"{wl['bitfield']}, {m} samples/view x 13 field evaluations",
                        "views_per_step": world, "sds_backward": args.sds_backward,
+                       "optimizer_steps_applied": applied, "grad_scaler_scale": scaler.get_scale(),
                        "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad all-reduce)"},
             "roofline": {"kernel": "k_scatter (hash-grid gradient scatter, fp32 atomics)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -170,7 +196,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "true bound is the L2 atomic request rate (~21 G 64-B requests/s, "
                                  "profiles/atomics_r01.txt), not HBM bandwidth; see DESIGN.md"},
-            "kernels_ms_per_step": {"k_scatter": sum(sc) / args.steps, "k_grid_encode": sum(en) / args.steps},
+            "kernels_ms_per_step": {k: sum(a.elapsed_time(b) for a, b in v) / args.steps
+                                    for k, v in prof.items() if not k.endswith("_evals")},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
