@@ -135,14 +135,15 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
                              uint32_t log2_hashmap_size, float step, float *grad_params, void *stream);
 
-/* The same scatter without global atomics on the big (hashed) levels: every corner contribution is appended as a
- * 12-byte record to the region of its 64-KB gradient bin, then each bin is accumulated in LDS (see hashgrid.hip).
+/* The same scatter without global atomics: every corner contribution (equal-cell runs of neighbouring samples
+ * summed first on the coarse levels) is appended as a 12-byte record to the region of its 64-KB gradient bin, then
+ * each bin is accumulated in LDS and added to the table (see hashgrid.hip).
  * `dout_planes` is level-major [n_levels][n*P][2] (what mi3d_mlp_backward writes with dx_planes != 0).
  * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
- * it; with workspace == NULL or too small for even 64 samples everything falls back to the atomic path.
- * mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice (0: nothing to bin). */
-size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, uint32_t n_levels, uint32_t base_resolution,
-                                          float per_level_scale, uint32_t log2_hashmap_size);
+ * it; with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
+ * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice. */
+size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
+                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size);
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                              uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,

@@ -205,6 +205,97 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
     }
 }
 
+// ---------------------------------------------------------------- backward, coarse levels ("runs" kernel)
+// Levels whose cells are longer than a marching step: consecutive samples of a ray (= consecutive lanes) sit in the
+// same cell for a whole RUN of lanes.  Lane = sample, so cell and weights are computed once per point (the quad kernel
+// above computes them four times); the 16 corner values of every lane go to an LDS slab, then the wave is re-used as
+// 4 run-slots x 16 values: lane (r, i) sums value i over the lanes of run r (sequential LDS reads, deterministic
+// order) and ONE atomic instruction adds the 4 runs' 16 dwords each - the 4 dwords of an x-neighbour pair leave in the
+// same request, like the quads of the kernel above.
+constexpr int kRunStride = 17;  // floats per lane in the slab (16 values, padded against bank conflicts)
+
+__global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uint32_t n, const float *__restrict__ dout,
+                                                                 GridTable T, uint32_t level_mask, uint32_t plane_rows,
+                                                                 uint32_t n_rep, size_t rep_stride, int debug,
+                                                                 float *__restrict__ grad_table) {
+    __shared__ float slab_all[kWaves][kWave * kRunStride];
+    __shared__ uint32_t cell_all[kWaves][kWave * 3];   // cell of every lane
+    __shared__ uint32_t start_all[kWaves][kWave + 1];  // first lane of run r (runs are numbered in lane order)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    float *slab = slab_all[wave];
+    uint32_t *cells = cell_all[wave], *starts = start_all[wave];
+    grad_table += (size_t)(blockIdx.x % n_rep) * rep_stride;
+    const uint32_t F = T.n_levels * 2;
+    const uint32_t s = (blockIdx.x * kWaves + wave) * kWave + lane;
+    const bool valid = s < n;
+    if (!__any(valid)) return;
+    float base[2][3];
+    load_bases(ps, s, valid, base);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        if (!((level_mask >> l) & 1u)) continue;
+        const GridLevel L = T.level[l];
+        float *lvl = grad_table + (size_t)L.offset * 2;
+        for (uint32_t p = 0; p < ps.P; ++p) {
+            const size_t row = (size_t)s * ps.P + p;
+            float d0 = 0.f, d1 = 0.f;
+            if (valid) {
+                const float2 dd = plane_rows ? reinterpret_cast<const float2 *>(dout)[(size_t)l * plane_rows + row]
+                                             : *reinterpret_cast<const float2 *>(dout + row * F + 2 * l);
+                d0 = dd.x; d1 = dd.y;
+            }
+            const bool has = valid && (d0 != 0.f || d1 != 0.f);
+            const unsigned long long act = __ballot(has);
+            if (act == 0ull) continue;
+            float q[3];
+            point_of(ps, base, p, q);
+            uint32_t cx, cy, cz;
+            float fx, fy, fz;
+            grid_cell(q[0], L.scale, cx, fx);
+            grid_cell(q[1], L.scale, cy, fy);
+            grid_cell(q[2], L.scale, cz, fz);
+            const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+            const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // the forward's product order
+            const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                slab[lane * kRunStride + 2 * k] = has ? wk[k] * d0 : 0.f;
+                slab[lane * kRunStride + 2 * k + 1] = has ? wk[k] * d1 : 0.f;
+            }
+            cells[lane * 3] = cx; cells[lane * 3 + 1] = cy; cells[lane * 3 + 2] = cz;
+            // run heads: an active lane whose predecessor is inactive or sits in another cell
+            const uint32_t px = __shfl_up(cx, 1, 64), py = __shfl_up(cy, 1, 64), pz = __shfl_up(cz, 1, 64);
+            const bool prev_has = (lane > 0) && ((act >> (lane - 1)) & 1ull);
+            const bool head = has && !(prev_has && px == cx && py == cy && pz == cz);
+            const unsigned long long heads = __ballot(head);
+            const uint32_t n_runs = (uint32_t)__popcll(heads);
+            if (head) starts[__popcll(heads & lt)] = (uint32_t)lane;
+            // a run ends where the next head begins or at the first inactive lane after its start
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t i = lane & 15u, slot = lane >> 4;
+            for (uint32_t r0 = 0; r0 < n_runs; r0 += 4) {
+                const uint32_t r = r0 + slot;
+                if (r < n_runs) {
+                    const uint32_t first = starts[r];
+                    // length: contiguous active, non-head lanes after `first`
+                    const unsigned long long stop = (~act | heads) & ~((2ull << first) - 1ull);  // bits above `first`
+                    const uint32_t end = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+                    float sum = 0.f;
+                    for (uint32_t j = first; j < end; ++j) sum += slab[j * kRunStride + i];
+                    const uint32_t k = i >> 1, f = i & 1u;
+                    const uint32_t e = grid_entry(L, cells[first * 3] + (k & 1u), cells[first * 3 + 1] + ((k >> 1) & 1u),
+                                                  cells[first * 3 + 2] + (k >> 2));
+                    if (debug & 4) { if (sum == 12345.678f) lvl[e] = sum; }
+                    else unsafeAtomicAdd(lvl + (size_t)e * 2 + f, sum);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 PointSet make_points(const float *x, const float *x2, const float *offsets_host, uint32_t P0, uint32_t P, float bound,
                      int mode) {
     PointSet ps;
@@ -221,9 +312,18 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
     if (merge_levels > T.n_levels) merge_levels = T.n_levels;
     const char *lm = getenv("MI3D_SCATTER_LMASK");  // profiling only: restrict the scatter to a subset of levels
     if (lm) level_mask &= (uint32_t)strtoul(lm, nullptr, 0);
-    if ((level_mask & ((1ull << T.n_levels) - 1)) == 0) return 0;
-    hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
-                       merge_levels, level_mask, plane_rows, n_rep, rep_stride, grad_params);
+    level_mask &= (uint32_t)((1ull << T.n_levels) - 1);
+    if (level_mask == 0) return 0;
+    // levels where neighbouring samples share cells go through the runs kernel (it has no device-side count)
+    static const int no_runs = getenv("MI3D_SCATTER_NO_RUNS") ? atoi(getenv("MI3D_SCATTER_NO_RUNS")) : 0;
+    const uint32_t runs_mask = (count == nullptr && !no_runs) ? (level_mask & ((1u << merge_levels) - 1u)) : 0u;
+    if (runs_mask)
+        hipLaunchKernelGGL(k_scatter_runs, dim3((n + kWave * kWaves - 1) / (kWave * kWaves)), dim3(kWave * kWaves), 0, st,
+                           ps, n, dout, T, runs_mask, plane_rows, n_rep, rep_stride,
+                           getenv("MI3D_BIN_DEBUG") ? atoi(getenv("MI3D_BIN_DEBUG")) : 0, grad_params);
+    if (level_mask & ~runs_mask)
+        hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
+                           merge_levels, level_mask & ~runs_mask, plane_rows, n_rep, rep_stride, grad_params);
     return (int)hipGetLastError();
 }
 
@@ -236,21 +336,27 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 }
 
 
-// ================================================================ binned scatter (no global atomics on the big levels)
+// ================================================================ binned scatter (no global atomics)
 //
-// The chip retires ~21 G atomic requests/s no matter what (profiles/atomics_r01.txt, atomics3_r01.txt), and on the
-// hashed levels nothing merges: 8 corners of every (sample, point) land in 4 random 64-byte blocks.  Plain stores and
-// LDS atomics are an order of magnitude cheaper, so the big levels go through memory instead:
+// The chip retires ~21 G atomic requests/s no matter what (profiles/atomics_r01.txt, atomics3_r01.txt): scope,
+// footprint and per-XCD private copies change nothing, and requests that hit one line serialise on top of that.  On
+// the hashed levels nothing merges (the 8 corners of every point land in 4 random 64-byte blocks), on the dense levels
+// every workgroup hammers the same few lines.  Plain stores and LDS integer atomics are an order of magnitude cheaper,
+// so the gradient goes through memory instead:
 //   pass 1 (k_bin_emit)   every corner contribution becomes a 12-byte record {entry, g0, g1} appended to the region
-//                         of its BIN (8192 consecutive entries = 64 KB of gradient) - one private region per
-//                         (wave, bin), so appends are a wave-private LDS counter and a plain store, no atomics;
-//                         the arena is wave-major ([wave][bin][cap]) so the 64 regions a wave is filling at any
-//                         moment (one level's bins) sit in one 4 MB span: two TLB pages instead of 64;
-//   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS
-//                         (ds_add_f32), then adds the 64 KB tile to the gradient table.
+//                         of its BIN (8192 consecutive entries of one level = 64 KB of gradient).  One private
+//                         region per (wave, bin): an append is a wave-private LDS counter and a plain store.  The
+//                         arena is wave-major so the regions a wave is filling at any moment (one level's bins) sit
+//                         in a few MB: a handful of TLB pages, and with 2048 emitting waves the lines being
+//                         appended to fit the L2s (measured: 8192 waves 40 ms, 2048 waves 28 ms per 5.4 M samples).
+//                         On levels whose cells are longer than a marching step, equal-cell RUNS of consecutive
+//                         lanes are summed first (through an LDS slab, see k_scatter_runs) and emit one record set.
+//   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS in
+//                         64-bit fixed point (LDS fp32 atomics retire 0.38 lanes/clk/CU, 64-bit integer ones 5.3:
+//                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
-constexpr uint32_t kEmitWavesMax = 2048, kReduceSplit = 4;  // 2048 waves: the lines being appended to fit the L2s
+constexpr uint32_t kEmitWavesMax = 2048, kReduceSplit = 4;
 
 struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index
@@ -258,56 +364,124 @@ struct __attribute__((packed, aligned(4))) BinRecord {
 };
 
 struct BinPlan {
-    uint32_t level_bin0[MI3D_MAX_LEVELS];  // first bin of each binned level
-    uint32_t binned_mask, n_bins, cap, n_waves;
+    uint32_t level_bin0[MI3D_MAX_LEVELS];   // first bin of each level (bins are numbered level by level)
+    uint32_t level_cap[MI3D_MAX_LEVELS];    // records one (wave, bin) region of that level holds
+    uint32_t level_waves[MI3D_MAX_LEVELS];  // emitting waves of that level (coarse levels: many, fine levels: 2048)
+    uint64_t level_base[MI3D_MAX_LEVELS];   // first record of the level in the arena; inside: [wave][bin][cap]
+    uint32_t level_cnt0[MI3D_MAX_LEVELS];   // first entry of the level in counts[]; inside: [wave][bin]
+    uint32_t level_max0[MI3D_MAX_LEVELS];   // first entry of the level in level_max[]; inside: [wave]
+    uint64_t total_records;
+    uint32_t total_counts, total_max;
+    uint32_t n_levels, n_bins;
     uint32_t debug;  // profiling only (MI3D_BIN_DEBUG): 1 = reduce skips the LDS adds, 2 = emit skips the record stores
 };
 
-inline bool level_is_binned(const GridLevel &L) { return L.size >= 8 * kBinEntries && L.size % kBinEntries == 0; }
+__host__ __device__ inline uint32_t level_bins(const GridLevel &L) { return (L.size + kBinEntries - 1) / kBinEntries; }
 
-inline BinPlan make_bin_plan(const GridTable &T) {
+inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
+    uint32_t nw = (uint32_t)(w < cap_waves ? w : cap_waves);
+    nw = (nw + kWaves - 1) / kWaves * kWaves;
+    return nw ? nw : kWaves;
+}
+
+// The plan for slices of n_slice samples.  Fine levels are emitted by at most 2048 waves (the lines being appended to
+// must fit the L2s); the coarse levels' run merging is latency-bound and emits few records, so it gets up to 16384.
+// Region capacities - hashed levels: the uniform share of the UNMERGED record count plus 25 % (the hash spreads them
+// evenly).  Dense levels: bins are spatial, a wave's samples cluster in few of them, and merging thins the records by
+// an unknown factor: the share assumes a quarter of the geometric run length and two-fold imbalance.  A full region is
+// not an error - the overflow goes to the table by atomics.
+inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels) {
+    static const uint32_t fine_waves = getenv("MI3D_BIN_WAVES") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES")) : kEmitWavesMax;
+    static const uint32_t coarse_waves =
+        getenv("MI3D_BIN_WAVES_COARSE") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES_COARSE")) : 16384u;
     BinPlan p{};
+    p.n_levels = T.n_levels;
+    const uint64_t tiles = (n_slice + kWave - 1) / kWave;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
+        const GridLevel &L = T.level[l];
+        const uint32_t bins = level_bins(L);
+        const bool merged = l < merge_levels;
+        p.level_waves[l] = round_waves(tiles, merged ? coarse_waves : fine_waves);
+        const double pts_per_wave = (double)n_slice * P / p.level_waves[l];
+        double per = pts_per_wave * 8.0 / bins;
+        if (L.hashed) {
+            per *= 1.25;
+        } else {
+            double run = merged ? (1.0 / (double)L.res) / (1.5 * (double)step01) / 4.0 : 1.0;
+            run = run < 1.0 ? 1.0 : run;
+            per = per / run * 2.0;
+        }
+        p.level_cap[l] = (uint32_t)per + 64u;
         p.level_bin0[l] = p.n_bins;
-        if (level_is_binned(T.level[l])) { p.binned_mask |= 1u << l; p.n_bins += T.level[l].size / kBinEntries; }
+        p.level_base[l] = p.total_records;
+        p.level_cnt0[l] = p.total_counts;
+        p.level_max0[l] = p.total_max;
+        p.n_bins += bins;
+        p.total_records += (uint64_t)p.level_waves[l] * bins * p.level_cap[l];
+        p.total_counts += p.level_waves[l] * bins;
+        p.total_max += p.level_waves[l];
     }
     return p;
+}
+inline size_t bin_workspace_bytes(const BinPlan &p) {
+    return (size_t)p.total_records * sizeof(BinRecord) + (size_t)p.total_counts * sizeof(uint32_t) +
+           (size_t)p.total_max * sizeof(float);
+}
+
+__device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel &L, uint32_t l, uint32_t gw, uint32_t e,
+                                            float g0, float g1, uint32_t *fill, BinRecord *__restrict__ arena,
+                                            float *__restrict__ grad_table, float &lmax) {
+    const uint32_t b = e >> kBinShift;
+    const uint32_t slot = atomicAdd(&fill[plan.level_bin0[l] + b], 1u);  // wave-private LDS counter
+    lmax = fmaxf(lmax, fmaxf(fabsf(g0), fabsf(g1)));
+    if (plan.debug & 2u) return;
+    if (slot < plan.level_cap[l]) {
+        BinRecord r{e, g0, g1};
+        arena[plan.level_base[l] + ((size_t)gw * level_bins(L) + b) * plan.level_cap[l] + slot] = r;
+    } else {  // region full: straight to the table
+        float *dst = grad_table + ((size_t)L.offset + e) * 2;
+        unsafeAtomicAdd(dst, g0);
+        unsafeAtomicAdd(dst + 1, g1);
+    }
 }
 
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
+                                                             uint32_t level_mask, uint32_t n_waves,
                                                              BinRecord *__restrict__ arena,
                                                              uint32_t *__restrict__ counts,
                                                              float *__restrict__ level_max,
                                                              float *__restrict__ grad_table) {
     extern __shared__ uint32_t fill_all[];  // [kWaves][n_bins] records appended so far by this wave
+    __shared__ float slab_all[kWaves][kWave * kRunStride];
+    __shared__ uint32_t cell_all[kWaves][kWave * 3];
+    __shared__ uint32_t start_all[kWaves][kWave + 1];
+    __shared__ float lmax_all[kWaves][MI3D_MAX_LEVELS];
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
     uint32_t *fill = fill_all + wave_in_wg * plan.n_bins;
+    float *slab = slab_all[wave_in_wg];
+    uint32_t *cells = cell_all[wave_in_wg], *starts = start_all[wave_in_wg];
     for (uint32_t b = lane; b < plan.n_bins; b += kWave) fill[b] = 0;
-    if (gw >= plan.n_waves) return;
-    const size_t region_stride = (size_t)plan.cap;
-    float vmax[MI3D_MAX_LEVELS];  // largest |record value| this lane emitted, per level (fixes the reduce's scale)
-#pragma unroll
-    for (int l = 0; l < MI3D_MAX_LEVELS; ++l) vmax[l] = 0.f;
+    if (lane < MI3D_MAX_LEVELS) lmax_all[wave_in_wg][lane] = 0.f;
+    if (gw >= n_waves) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
 
-    for (uint32_t s0 = s_begin + gw * kWave; s0 < s_end; s0 += plan.n_waves * kWave) {
+    for (uint32_t s0 = s_begin + gw * kWave; s0 < s_end; s0 += n_waves * kWave) {
         const uint32_t s = s0 + lane;
         const bool valid = s < s_end;
         float base[2][3];
         load_bases(ps, s, valid, base);
-#pragma unroll
-        for (uint32_t l = 0; l < (uint32_t)MI3D_MAX_LEVELS; ++l) {
-            if (l >= T.n_levels || !((plan.binned_mask >> l) & 1u)) continue;
+        for (uint32_t l = 0; l < T.n_levels; ++l) {
+            if (!((level_mask >> l) & 1u)) continue;
             const GridLevel L = T.level[l];
-            const uint32_t bin0 = plan.level_bin0[l];
+            const bool merge = l < merge_levels;
             float lmax = 0.f;
-            const float2 *plane = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows;
             // the gradient pairs are fetched three points ahead of their use (the loop is latency-bound otherwise)
             const float2 zero2 = make_float2(0.f, 0.f);
-            const float2 *prow = plane + (size_t)s * ps.P;
+            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + (size_t)s * ps.P;
             float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[1] : zero2,
                    d2 = (valid && 2 < ps.P) ? prow[2] : zero2;
             for (uint32_t p = 0; p < ps.P; ++p) {
@@ -315,7 +489,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 d0 = d1; d1 = d2;
                 d2 = (valid && p + 3 < ps.P) ? prow[p + 3] : zero2;
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
-                if (!__any(has)) continue;
+                const unsigned long long act = __ballot(has);
+                if (act == 0ull) continue;
                 float q[3];
                 point_of(ps, base, p, q);
                 uint32_t cx, cy, cz;
@@ -326,54 +501,75 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
                 const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                float v[16];
+                if (!merge) {  // fine level: every point is its own run, the lane emits its 8 corners
+                    if (has) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { v[2 * k] = wk[k] * d.x; v[2 * k + 1] = wk[k] * d.y; }
-                bool owner = has;
-                if (l < merge_levels) owner = wave_merge_runs<16>(has, CellKey{cx, cy, cz}, v, lane);
-                if (owner) {
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) {
-                        const uint32_t e = grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2));
-                        const uint32_t b = bin0 + (e >> kBinShift);
-                        const uint32_t slot = atomicAdd(&fill[b], 1u);  // wave-private LDS counter
-                        lmax = fmaxf(lmax, fmaxf(fabsf(v[2 * k]), fabsf(v[2 * k + 1])));
-                        if (plan.debug & 2u) continue;
-                        if (slot < plan.cap) {
-                            BinRecord r{e, v[2 * k], v[2 * k + 1]};
-                            arena[((size_t)gw * plan.n_bins + b) * region_stride + slot] = r;
-                        } else {  // region full (cannot happen with the sizing below unless the hash is adversarial)
-                            float *dst = grad_table + ((size_t)L.offset + e) * 2;
-                            unsafeAtomicAdd(dst, v[2 * k]);
-                            unsafeAtomicAdd(dst + 1, v[2 * k + 1]);
+                        for (uint32_t k = 0; k < 8; ++k) {
+                            const uint32_t e = grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2));
+                            emit_record(plan, L, l, gw, e, wk[k] * d.x, wk[k] * d.y, fill, arena, grad_table, lmax);
                         }
                     }
+                    continue;
                 }
+                // coarse level: sum equal-cell runs of consecutive lanes through the slab (see k_scatter_runs)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    slab[lane * kRunStride + 2 * k] = has ? wk[k] * d.x : 0.f;
+                    slab[lane * kRunStride + 2 * k + 1] = has ? wk[k] * d.y : 0.f;
+                }
+                cells[lane * 3] = cx; cells[lane * 3 + 1] = cy; cells[lane * 3 + 2] = cz;
+                const uint32_t px = __shfl_up(cx, 1, 64), py = __shfl_up(cy, 1, 64), pz = __shfl_up(cz, 1, 64);
+                const bool prev_has = (lane > 0) && ((act >> (lane - 1)) & 1ull);
+                const bool head = has && !(prev_has && px == cx && py == cy && pz == cz);
+                const unsigned long long heads = __ballot(head);
+                const uint32_t n_runs = (uint32_t)__popcll(heads);
+                if (head) starts[__popcll(heads & lt)] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t i = lane & 15u, rs = lane >> 4;
+                for (uint32_t r0 = 0; r0 < n_runs; r0 += 4) {
+                    const uint32_t r = r0 + rs;
+                    float sum = 0.f;
+                    uint32_t first = 0;
+                    if (r < n_runs) {
+                        first = starts[r];
+                        const unsigned long long stop = (~act | heads) & ~((2ull << first) - 1ull);
+                        const uint32_t end = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+                        for (uint32_t j = first; j < end; ++j) sum += slab[j * kRunStride + i];
+                    }
+                    const float other = __shfl_xor(sum, 1, 64);  // feature 1 of the same corner (all lanes take part)
+                    if (r < n_runs && (i & 1u) == 0u) {
+                        const uint32_t k = i >> 1;
+                        const uint32_t e = grid_entry(L, cells[first * 3] + (k & 1u), cells[first * 3 + 1] + ((k >> 1) & 1u),
+                                                      cells[first * 3 + 2] + (k >> 2));
+                        if (sum != 0.f || other != 0.f)
+                            emit_record(plan, L, l, gw, e, sum, other, fill, arena, grad_table, lmax);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            vmax[l] = fmaxf(vmax[l], lmax);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+            if (lane == 0) lmax_all[wave_in_wg][l] = fmaxf(lmax_all[wave_in_wg][l], lmax);
         }
     }
     for (uint32_t b = lane; b < plan.n_bins; b += kWave) {
-        const uint32_t c = fill[b];
-        counts[(size_t)gw * plan.n_bins + b] = c < plan.cap ? c : plan.cap;
+        uint32_t lvl = 0;
+        for (uint32_t l = 0; l < plan.n_levels; ++l)
+            if (plan.level_bin0[l] <= b) lvl = l;
+        if (!((level_mask >> lvl) & 1u)) continue;
+        const uint32_t c = fill[b], cap = plan.level_cap[lvl], bins = level_bins(T.level[lvl]);
+        counts[plan.level_cnt0[lvl] + (size_t)gw * bins + (b - plan.level_bin0[lvl])] = c < cap ? c : cap;
     }
-#pragma unroll
-    for (int l = 0; l < MI3D_MAX_LEVELS; ++l) {
-        float m = vmax[l];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        if (lane == 0) level_max[(size_t)gw * MI3D_MAX_LEVELS + l] = m;
-    }
+    if (lane < MI3D_MAX_LEVELS && lane < (int)plan.n_levels && ((level_mask >> lane) & 1u))
+        level_max[plan.level_max0[lane] + gw] = lmax_all[wave_in_wg][lane];
 }
 
 constexpr int kReduceWaves = 16;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
 
-// LDS fp32 atomic adds retire 0.38 lanes/clk/CU on gfx950, 64-bit integer ones 5.3 (tools/lds_atomics_bench.hip,
-// profiles/lds_atomics_r01.txt), so the bin is accumulated in 64-bit FIXED POINT: every record value is scaled by a
-// power of two 2^k chosen from the largest |value| any wave emitted for the level (|v| 2^k < 2^38, so 2^24 records
-// cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is exact; what is dropped is whatever
-// lies more than 38 binary digits below the level's largest contribution - far below what fp32 running sums (24
-// digits) or the reference's fp16 autocast gradients resolve.
+// Every record value is scaled by a power of two 2^k chosen from the largest |value| any wave emitted for the level
+// (|v| 2^k < 2^38, so 2^24 records cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is
+// exact; what is dropped is whatever lies more than 38 binary digits below the level's largest contribution - far
+// below what fp32 running sums (24 digits) or the reference's fp16 autocast gradients resolve.
 __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRecord *__restrict__ arena,
                                                                      const uint32_t *__restrict__ counts,
                                                                      const float *__restrict__ level_max, GridTable T,
@@ -385,10 +581,12 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRec
     const uint32_t wave_in_wg = threadIdx.x / kWave;
     uint32_t lvl = 0;  // which level does this bin belong to?  (uniform scan of at most 16 entries)
     for (uint32_t l = 0; l < T.n_levels; ++l)
-        if (((plan.binned_mask >> l) & 1u) && plan.level_bin0[l] <= b) lvl = l;
+        if (plan.level_bin0[l] <= b) lvl = l;
+    const uint32_t cap = plan.level_cap[lvl], n_waves = plan.level_waves[lvl], bins = level_bins(T.level[lvl]);
+    const uint32_t lb = b - plan.level_bin0[lvl];
     for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) acc[i] = 0ull;
     float m = 0.f;
-    for (uint32_t r = threadIdx.x; r < plan.n_waves; r += blockDim.x) m = fmaxf(m, level_max[(size_t)r * MI3D_MAX_LEVELS + lvl]);
+    for (uint32_t r = threadIdx.x; r < n_waves; r += blockDim.x) m = fmaxf(m, level_max[plan.level_max0[lvl] + r]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) wg_max[wave_in_wg] = m;
@@ -405,9 +603,9 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRec
 
     bool any = false;
     constexpr uint32_t U = 4;  // records in flight per lane
-    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < plan.n_waves; r += kReduceSplit * kReduceWaves) {
-        const uint32_t cnt = counts[(size_t)r * plan.n_bins + b];
-        const BinRecord *src = arena + ((size_t)r * plan.n_bins + b) * plan.cap;
+    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += kReduceSplit * kReduceWaves) {
+        const uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
+        const BinRecord *src = arena + plan.level_base[lvl] + ((size_t)r * bins + lb) * cap;
         for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
             BinRecord rec[U];
 #pragma unroll
@@ -429,8 +627,10 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRec
         any |= cnt != 0;
     }
     if (!__syncthreads_or((int)any)) return;
-    float *dst = grad_table + ((size_t)T.level[lvl].offset + (size_t)(b - plan.level_bin0[lvl]) * kBinEntries) * 2;
-    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) {
+    const uint32_t e0 = lb * kBinEntries;
+    const uint32_t live = T.level[lvl].size - e0 < kBinEntries ? T.level[lvl].size - e0 : kBinEntries;  // last bin of a level
+    float *dst = grad_table + ((size_t)T.level[lvl].offset + e0) * 2;
+    for (uint32_t i = threadIdx.x; i < live * 2; i += blockDim.x) {
         const long long a = (long long)acc[i];
         if (a != 0) unsafeAtomicAdd(dst + i, (float)((double)a * unscale));
     }
@@ -446,41 +646,7 @@ __global__ void k_replica_reduce(const float *__restrict__ rep, uint32_t n_rep, 
     if (s != 0.f) grad_table[i] += s;
 }
 
-constexpr uint32_t kReplicas = 64;
-// entries of the table prefix made of the levels that are NOT binned (0 when those levels are not a prefix)
-inline uint32_t unbinned_prefix_entries(const GridTable &T, const BinPlan &plan) {
-    uint32_t l = 0, entries = 0;
-    while (l < T.n_levels && !((plan.binned_mask >> l) & 1u)) { entries = T.level[l].offset + T.level[l].size; ++l; }
-    for (uint32_t k = l; k < T.n_levels; ++k)
-        if (!((plan.binned_mask >> k) & 1u)) return 0;
-    return entries;
-}
-
-// records one (bin, wave) region must hold for a slice of n_slice samples, with 25 % head room over the uniform share
-inline uint32_t bin_region_cap(uint64_t n_slice, uint32_t P, uint32_t bins_per_level, uint32_t n_waves) {
-    const uint64_t per = (n_slice * P * 8 + (uint64_t)bins_per_level * n_waves - 1) / ((uint64_t)bins_per_level * n_waves);
-    return (uint32_t)(per + per / 4 + 64);
-}
-inline uint32_t emit_waves_for(uint64_t n) {
-    const uint64_t w = (n + kWave - 1) / kWave;
-    static const uint32_t cap_waves = getenv("MI3D_BIN_WAVES") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES")) : kEmitWavesMax;
-    uint32_t nw = (uint32_t)(w < cap_waves ? w : cap_waves);
-    nw = (nw + kWaves - 1) / kWaves * kWaves;
-    return nw ? nw : kWaves;
-}
-inline uint32_t min_bins_per_level(const GridTable &T, const BinPlan &plan) {
-    uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t l = 0; l < T.n_levels; ++l)
-        if ((plan.binned_mask >> l) & 1u) { const uint32_t b = T.level[l].size / kBinEntries; m = b < m ? b : m; }
-    return m;
-}
-inline size_t bin_workspace_bytes(const BinPlan &plan, uint32_t cap, uint32_t n_waves) {
-    return (size_t)plan.n_bins * n_waves * ((size_t)cap * sizeof(BinRecord) + sizeof(uint32_t)) +
-           (size_t)n_waves * MI3D_MAX_LEVELS * sizeof(float);
-}
-inline size_t replica_bytes(const GridTable &T, const BinPlan &plan) {
-    return (size_t)kReplicas * unbinned_prefix_entries(T, plan) * 2 * sizeof(float);
-}
+static const uint32_t kReplicas = getenv("MI3D_REPLICAS") ? (uint32_t)atoi(getenv("MI3D_REPLICAS")) : 64u;
 
 }  // namespace
 
@@ -557,15 +723,13 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
     return launch_scatter(ps, n, count, dout, T, default_merge_levels(T, step01), grad_params, as_stream(stream));
 }
 
-size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, uint32_t n_levels, uint32_t base_resolution,
-                                          float per_level_scale, uint32_t log2_hashmap_size) {
+size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
+                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || n == 0) return 0;
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
-    const BinPlan plan = make_bin_plan(T);
-    if (plan.n_bins == 0) return 0;
-    const uint32_t nw = emit_waves_for(n);
-    return bin_workspace_bytes(plan, bin_region_cap(n, P, min_bins_per_level(T, plan), nw), nw) + replica_bytes(T, plan);
+    const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
+    return bin_workspace_bytes(plan_for(T, n, P, step01, default_merge_levels(T, step01)));
 }
 
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
@@ -582,48 +746,34 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     const uint32_t merge_levels = default_merge_levels(T, step01);
-    BinPlan plan = make_bin_plan(T);
     const uint32_t plane_rows = n * P;
 
-    // the tail of the workspace holds the private copies of the unbinned (dense) levels
-    const size_t rep_bytes = plan.n_bins ? replica_bytes(T, plan) : 0;
-    float *rep = nullptr;
-    if (workspace != nullptr && rep_bytes != 0 && workspace_bytes > rep_bytes) {
-        workspace_bytes -= rep_bytes;
-        rep = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + workspace_bytes);
-    }
-    // choose the slice: the largest sample count whose record arena fits the workspace
-    plan.n_waves = emit_waves_for(n);
-    const uint32_t bpl = plan.n_bins ? min_bins_per_level(T, plan) : 1;
+    // the slice: the largest sample count (halving from n) whose record arena fits the workspace
     uint64_t n_slice = n;
-    if (plan.n_bins) {
-        while (n_slice > kWave && bin_workspace_bytes(plan, bin_region_cap(n_slice, P, bpl, plan.n_waves), plan.n_waves) >
-                                      workspace_bytes)
-            n_slice = (n_slice + 1) / 2;
-        if (workspace == nullptr ||
-            bin_workspace_bytes(plan, bin_region_cap(n_slice, P, bpl, plan.n_waves), plan.n_waves) > workspace_bytes)
-            plan.n_bins = 0;  // no usable workspace: everything goes through the atomic path
+    BinPlan plan = plan_for(T, n_slice, P, step01, merge_levels);
+    while (n_slice > kWave && bin_workspace_bytes(plan) > workspace_bytes) {
+        n_slice = (n_slice + 1) / 2;
+        plan = plan_for(T, n_slice, P, step01, merge_levels);
     }
-    const uint32_t atomic_mask = plan.n_bins ? ~plan.binned_mask : 0xFFFFFFFFu;
-    int err;
-    if (plan.n_bins && rep != nullptr) {
-        const uint32_t prefix = unbinned_prefix_entries(T, plan);
-        (void)hipMemsetAsync(rep, 0, rep_bytes, st);
-        err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, rep, st, atomic_mask, plane_rows, kReplicas,
-                             (size_t)prefix * 2);
-        hipLaunchKernelGGL(k_replica_reduce, dim3((prefix * 2 + 255) / 256), dim3(256), 0, st, rep, kReplicas,
-                           (size_t)prefix * 2, prefix * 2, grad_params);
-    } else {
-        err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, grad_params, st, atomic_mask, plane_rows);
+    if (workspace == nullptr || bin_workspace_bytes(plan) > workspace_bytes) {
+        // no usable workspace: the atomic kernels, with private copies of the table against same-line serialisation
+        // when the caller's scratch at least holds those
+        const size_t rep_bytes = (size_t)kReplicas * T.n_entries * 2 * sizeof(float);
+        if (workspace != nullptr && workspace_bytes >= rep_bytes && rep_bytes < ((size_t)2 << 30)) {
+            float *rep = reinterpret_cast<float *>(workspace);
+            (void)hipMemsetAsync(rep, 0, rep_bytes, st);
+            const int err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, rep, st, 0xFFFFFFFFu, plane_rows,
+                                           kReplicas, (size_t)T.n_entries * 2);
+            hipLaunchKernelGGL(k_replica_reduce, dim3((T.n_entries * 2 + 255) / 256), dim3(256), 0, st, rep, kReplicas,
+                               (size_t)T.n_entries * 2, T.n_entries * 2, grad_params);
+            return err ? err : (int)hipGetLastError();
+        }
+        return launch_scatter(ps, n, nullptr, dout_planes, T, merge_levels, grad_params, st, 0xFFFFFFFFu, plane_rows);
     }
-    if (err != 0 || plan.n_bins == 0) return err;
-
-    plan.cap = bin_region_cap(n_slice, P, bpl, plan.n_waves);
     plan.debug = getenv("MI3D_BIN_DEBUG") ? (uint32_t)atoi(getenv("MI3D_BIN_DEBUG")) : 0u;
     BinRecord *arena = reinterpret_cast<BinRecord *>(workspace);
-    uint32_t *counts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(workspace) +
-                                                    (size_t)plan.n_bins * plan.n_waves * plan.cap * sizeof(BinRecord));
-    float *level_max = reinterpret_cast<float *>(counts + (size_t)plan.n_bins * plan.n_waves);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(arena + plan.total_records);
+    float *level_max = reinterpret_cast<float *>(counts + plan.total_counts);
     const size_t lds = (size_t)kWaves * plan.n_bins * sizeof(uint32_t);
     const size_t lds_reduce = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
     static bool attr_set = false;
@@ -632,15 +782,26 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                                   (int)lds_reduce);
         attr_set = true;
     }
+    // levels that share a writer-wave count go in one emit launch (two groups: coarse and fine)
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
-        hipLaunchKernelGGL(k_bin_emit, dim3(plan.n_waves / kWaves), dim3(kWave * kWaves), lds, st, ps, (uint32_t)s0, s1,
-                           dout_planes, plane_rows, T, plan, merge_levels, arena, counts, level_max, grad_params);
+        uint32_t todo = (uint32_t)((1ull << T.n_levels) - 1);
+        while (todo) {
+            const uint32_t l0 = (uint32_t)__builtin_ctz(todo);
+            uint32_t mask = 0;
+            for (uint32_t l = l0; l < T.n_levels; ++l)
+                if (((todo >> l) & 1u) && plan.level_waves[l] == plan.level_waves[l0] &&
+                    (l < merge_levels) == (l0 < merge_levels))
+                    mask |= 1u << l;
+            todo &= ~mask;
+            hipLaunchKernelGGL(k_bin_emit, dim3(plan.level_waves[l0] / kWaves), dim3(kWave * kWaves), lds, st, ps, (uint32_t)s0,
+                               s1, dout_planes, plane_rows, T, plan, merge_levels, mask, plan.level_waves[l0], arena, counts,
+                               level_max, grad_params);
+        }
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
                            counts, level_max, T, plan, grad_params);
     }
     return (int)hipGetLastError();
 }
-
 
 }  // extern "C"

@@ -67,7 +67,7 @@ def lib():
         _lib.mi3d_hashgrid_levels.restype = u32
         _lib.mi3d_hashgrid_levels.argtypes = [u32, u32, f32, u32, vp, vp, vp]
         _lib.mi3d_grid_scatter_binned_workspace.restype = C.c_size_t
-        _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, u32, u32, f32, u32]
+        _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, f32, f32, u32, u32, f32, u32]
     return _lib
 
 

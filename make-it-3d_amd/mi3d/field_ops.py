@@ -56,8 +56,9 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     lib = L.lib()
     ws, ws_bytes = None, 0
     if workspace_bytes != 0 and n > 0:
-        needed = lib.mi3d_grid_scatter_binned_workspace(n, P, cfg["n_levels"], cfg["base_resolution"],
-                                                        cfg["per_level_scale"], cfg["log2_hashmap_size"])
+        needed = lib.mi3d_grid_scatter_binned_workspace(n, P, float(bound), float(step), cfg["n_levels"],
+                                                        cfg["base_resolution"], cfg["per_level_scale"],
+                                                        cfg["log2_hashmap_size"])
         if workspace_bytes is not None:
             needed = min(needed, int(workspace_bytes))
             ws = torch.empty(needed, dtype=torch.uint8, device=x.device) if needed else None

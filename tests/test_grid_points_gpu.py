@@ -147,7 +147,7 @@ def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace
     if ws == "tiny":  # room for about a third of the samples per slice
         import ctypes
         from mi3d import _lib
-        need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 16, 16, ctypes.c_float(cfg.per_level_scale), 19)
+        need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19)
         ws = int(need)
     g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda) if second else None, offs, P0, bound, T(planes, cuda), kcfg,
                                  0.0034, cfg.n_params, workspace_bytes=ws).cpu().numpy()
