@@ -448,8 +448,8 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
-                                                             uint32_t level_mask, uint32_t n_waves,
-                                                             BinRecord *__restrict__ arena,
+                                                             uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
+                                                             uint32_t waves_b, BinRecord *__restrict__ arena,
                                                              uint32_t *__restrict__ counts,
                                                              float *__restrict__ level_max,
                                                              float *__restrict__ grad_table) {
@@ -460,7 +460,13 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
     __shared__ float lmax_all[kWaves][MI3D_MAX_LEVELS];
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
+    // two roles in one launch: the first waves_a waves emit the levels of mask_a (the fine, store-bound group: they are
+    // dispatched first and take their 2 workgroups per CU), the next waves_b waves the levels of mask_b (the coarse,
+    // latency-bound group, which fills the rest of the machine and hides under the first)
+    uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
+    const bool role_b = gw >= waves_a;
+    if (role_b) gw -= waves_a;
+    const uint32_t level_mask = role_b ? mask_b : mask_a, n_waves = role_b ? waves_b : waves_a;
     uint32_t *fill = fill_all + wave_in_wg * plan.n_bins;
     float *slab = slab_all[wave_in_wg];
     uint32_t *cells = cell_all[wave_in_wg], *starts = start_all[wave_in_wg];
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const BinRec
     const double unscale = ldexp(1.0, -k);
 
     bool any = false;
-    constexpr uint32_t U = 4;  // records in flight per lane
+    constexpr uint32_t U = 8;  // records in flight per lane
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += kReduceSplit * kReduceWaves) {
         const uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
         const BinRecord *src = arena + plan.level_base[lvl] + ((size_t)r * bins + lb) * cap;
@@ -782,22 +788,16 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                                   (int)lds_reduce);
         attr_set = true;
     }
-    // levels that share a writer-wave count go in one emit launch (two groups: coarse and fine)
+    // the fine levels (>= merge_levels) and the coarse ones are two roles of one emit launch
+    const uint32_t all = (uint32_t)((1ull << T.n_levels) - 1);
+    const uint32_t coarse_mask = merge_levels ? (all & ((1u << merge_levels) - 1u)) : 0u, fine_mask = all & ~coarse_mask;
+    const uint32_t fine_waves = fine_mask ? plan.level_waves[__builtin_ctz(fine_mask)] : 0u;
+    const uint32_t coarse_waves = coarse_mask ? plan.level_waves[__builtin_ctz(coarse_mask)] : 0u;
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
-        uint32_t todo = (uint32_t)((1ull << T.n_levels) - 1);
-        while (todo) {
-            const uint32_t l0 = (uint32_t)__builtin_ctz(todo);
-            uint32_t mask = 0;
-            for (uint32_t l = l0; l < T.n_levels; ++l)
-                if (((todo >> l) & 1u) && plan.level_waves[l] == plan.level_waves[l0] &&
-                    (l < merge_levels) == (l0 < merge_levels))
-                    mask |= 1u << l;
-            todo &= ~mask;
-            hipLaunchKernelGGL(k_bin_emit, dim3(plan.level_waves[l0] / kWaves), dim3(kWave * kWaves), lds, st, ps, (uint32_t)s0,
-                               s1, dout_planes, plane_rows, T, plan, merge_levels, mask, plan.level_waves[l0], arena, counts,
-                               level_max, grad_params);
-        }
+        hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
+                           (uint32_t)s0, s1, dout_planes, plane_rows, T, plan, merge_levels, fine_mask, fine_waves, coarse_mask,
+                           coarse_waves, arena, counts, level_max, grad_params);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
                            counts, level_max, T, plan, grad_params);
     }
