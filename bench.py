@@ -14,9 +14,10 @@ degrees) and the NeRF gradients are averaged with one flat RCCL all-reduce per s
 ranks per second (weak scaling).
 
 The JSON line also carries
-  roofline     : the dominant kernel (hash-grid gradient scatter, `k_scatter`) - algorithmic bytes per launch
-                 (2048 B per encoder evaluation = 16 levels x 8 corners x 2 floats, read-modify-write)
-                 over its average launch duration measured with HIP events on the launch stream during the timed steps;
+  roofline     : the dominant single kernel (the 13-point hash-grid gather, `k_grid_encode`) - algorithmic bytes per
+                 launch (1024 B per field evaluation = 16 levels x 8 corners x 2 floats) over its average
+                 launch duration measured with HIP events on the launch stream during the timed steps; the other hot
+                 kernels (gradient scatter, MLP forward/backward) are listed the same way under rooflines_other;
   cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) rendering a bounded ray sample of the
                  same workload on this box's host cores, extrapolated to a full view (forward render only).
 """
@@ -43,7 +44,21 @@ WORKLOADS = {
     "small": dict(H=32, W=32, max_steps=128, bitfield="dense"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-SCATTER_BYTES_PER_EVAL = 2048
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, same guide
+ENCODE_BYTES_PER_EVAL = 1024   # 16 levels x 8 corners x 2 features x 4 B gathered per field evaluation
+SCATTER_BYTES_PER_EVAL = 2048  # the same bytes read-modify-written by the gradient scatter
+
+
+def pmc_traffic(kernel, workload, evals):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_r01.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of tools/encode_bench.py on this workload, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's evaluation count; None if not collected."""
+    path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+    try:
+        rec = json.load(open(path))[kernel][workload]
+        return rec["hbm_bytes_per_eval"] * evals
+    except Exception:
+        return None
 
 
 def cpu_baseline(wl, budget_s=20.0):
@@ -171,13 +186,41 @@ def main():
         raise SystemExit(f"bench invalid: only {applied} of {args.steps} timed steps applied their optimizer update "
                          f"(GradScaler overflow, scale now {scaler.get_scale()})")
     if rank == 0:
-        sc = [a.elapsed_time(b) for a, b in prof["scatter"]]
-        en = [a.elapsed_time(b) for a, b in prof["encode"]]
-        evals = [e for e in prof.get("scatter_evals", [])]
-        sc_ms = sum(sc) / max(len(sc), 1)
         P = 13
-        alg_bytes = (sum(evals) / max(len(evals), 1)) * SCATTER_BYTES_PER_EVAL if evals else m * P * SCATTER_BYTES_PER_EVAL
-        achieved = alg_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
+        ms = {k: [a.elapsed_time(b) for a, b in v] for k, v in prof.items() if not k.endswith("_evals")}
+        avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in ms.items()}
+        evals = float(m) * P if not prof.get("encode_evals") else sum(prof["encode_evals"]) / len(prof["encode_evals"])
+
+        def hbm_roof(kernel, key, bytes_per_eval, note):
+            t = avg.get(key, 0.0)
+            a = evals * bytes_per_eval / (t * 1e-3) / 1e9 if t > 0 else 0.0
+            return {"kernel": kernel, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": a / HBM_PEAK_GBPS, "traffic": None, "launches": len(ms.get(key, [])), "avg_launch_ms": t,
+                    "algorithmic_bytes_per_launch": evals * bytes_per_eval, "note": note}
+
+        def mfma_roof(kernel, key, flop_per_eval):
+            t = avg.get(key, 0.0)
+            a = evals * flop_per_eval / (t * 1e-3) / 1e12 if t > 0 else 0.0
+            return {"kernel": kernel, "bound": "mfma", "achieved": a, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": a / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(ms.get(key, [])),
+                    "avg_launch_ms": t, "algorithmic_flop_per_launch": evals * flop_per_eval}
+
+        # the dominant single kernel of the step: the stencil hash-grid gather (one launch per step, timed with HIP
+        # events on the launch stream); SURVEY 8(d): 16 levels x 8 corners x 8 B = 1024 B per field evaluation
+        roof = hbm_roof("k_grid_encode_planes (13-point hash-grid gather, one level pair per XCD, csrc/hashgrid.hip)", "encode",
+                        ENCODE_BYTES_PER_EVAL,
+                        "each XCD gathers from one L2-resident level at a time (FETCH_SIZE 16 GB/launch vs 191 GB for the "
+                        "all-levels kernel); the limit is the texture-address rate for divergent 8-byte gathers (about "
+                        "one line per clock per CU), HBM traffic is essentially the 128 B/evaluation feature write")
+        roof["traffic"] = pmc_traffic("k_grid_encode_planes", args.workload, evals)
+        others = [
+            hbm_roof("grid gradient scatter = k_bin_emit + k_bin_reduce per slice (records through HBM, no global "
+                     "atomics)", "scatter", SCATTER_BYTES_PER_EVAL,
+                     "algorithmic bytes = 2048 B/evaluation read-modify-write of the table; the binned path instead "
+                     "moves 8 records x 12 B per (evaluation, level) out and back"),
+            mfma_roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0),
+            mfma_roof("k_mlp_backward<F16> (recompute + dgrad + wgrad, both orientations)", "mlp_bwd", 25600.0),
+        ]
         line = {
             "metric": "SDS train-steps/sec (NeRF render+SD U-Net fwd+bwd) @128x128",
             "value": world * args.steps / elapsed, "unit": "view-steps/s", "n_gpus": world, "steps": args.steps,
@@ -190,14 +233,9 @@ def main():
                        "views_per_step": world, "sds_backward": args.sds_backward,
                        "optimizer_steps_applied": applied, "grad_scaler_scale": scaler.get_scale(),
                        "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad all-reduce)"},
-            "roofline": {"kernel": "k_scatter (hash-grid gradient scatter, fp32 atomics)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "launches": len(sc), "avg_launch_ms": sc_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "true bound is the L2 atomic request rate (~21 G 64-B requests/s, "
-                                 "profiles/atomics_r01.txt), not HBM bandwidth; see DESIGN.md"},
-            "kernels_ms_per_step": {k: sum(a.elapsed_time(b) for a, b in v) / args.steps
-                                    for k, v in prof.items() if not k.endswith("_evals")},
+            "roofline": roof,
+            "rooflines_other": others,
+            "kernels_ms_per_step": {k: sum(v) / args.steps for k, v in ms.items()},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

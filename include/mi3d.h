@@ -130,6 +130,13 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
                             const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *params,
                             uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
                             uint32_t log2_hashmap_size, float *out, void *stream);
+/* mi3d_grid_encode_points with level-major output planes [n_levels][n*P][2] (feature pair of level l, row r at
+ * out_planes[(l*n*P + r)*2]) - the layout the MLP kernels take with x_planes != 0.  Workgroups are tied to level pairs
+ * by XCD so each XCD's L2 only ever holds the tables of the level it is gathering from. */
+int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                                   uint32_t P, float bound, const float *params, uint32_t n_levels,
+                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                                   float *out_planes, void *stream);
 int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
                              const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
@@ -152,21 +159,23 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 
 /* network_tcnn.py:13-32: y = W3 relu(W2 relu(W1 x + b1) + b2) + b3, torch nn.Linear layout (W_l is [out_l, in_l]
- * row-major fp32, the master weights).  x [n, dim_in] fp32, out [n, dim_out] fp32.
+ * row-major fp32, the master weights).  x [n, dim_in] fp32 rows, or with x_planes != 0 level-major planes
+ * [dim_in/2][n][2]; out [n, dim_out] fp32.
  * half_mode != 0 reproduces torch.autocast(float16) around the stack (nerf/utils.py:979): inputs, weights, biases
  * and every layer output are rounded to binary16, products accumulate in fp32 (v_mfma_f32_32x32x16_f16);
  * half_mode == 0 is exact fp32 (v_mfma_f32_32x32x2_f32).  Supported shape: dim_in 32, dim_hidden 64, dim_out 4,
  * three layers (what network_tcnn.py:67 builds for the default 16-level grid); anything else returns
  * hipErrorInvalidValue - ask mi3d_mlp_supported() first. */
 int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, uint32_t num_layers);
-int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+int mi3d_mlp_forward(const float *x, int x_planes, uint32_t n, const float *W1, const float *b1, const float *W2,
+                     const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream);
 /* Backward of the above for upstream gradient dout [n, dim_out]: writes dx and ACCUMULATES the weight and bias
  * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
  * dx_planes == 0: dx is [n, dim_in] rows; dx_planes != 0: dx is level-major planes [dim_in/2][n][2] (feature pair
  * (2l, 2l+1) of row r at dx[(l*n + r)*2]), the layout mi3d_grid_scatter_binned consumes. */
-int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float *W1, const float *b1,
+int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
                       uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
                       float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream);

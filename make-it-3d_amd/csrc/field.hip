@@ -153,17 +153,29 @@ __device__ void build_blocks(char *lds, float *bias /* [HID + HID + 32] */, cons
 }
 
 // ---------------------------------------------------------------- tile pieces
-// rows of the tile as a K-block (kind X): lane (p, h) holds features 16 h .. 16 h + 15 of row row0 + p
+// rows of the tile as a K-block (kind X): lane (p, h) holds features 16 h .. 16 h + 15 of row row0 + p.
+// x is either [n, DIN] rows or (planes) level-major [DIN/2][n][2]: feature pair (2l, 2l+1) of row r at x[(l n + r) 2].
 template <class P>
-__device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, bool valid, int h) {
+__device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, bool valid, int h,
+                                                       bool planes, size_t n) {
     typename P::KB k;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
+    if (!planes) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (valid) t = src[c];
+        for (int c = 0; c < 4; ++c) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (valid) t = src[c];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) P::set(k, 4 * c + i, t[i]);
+            for (int i = 0; i < 4; ++i) P::set(k, 4 * c + i, t[i]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // 32 consecutive rows of one plane per load: 256 contiguous bytes per lane-half
+            f32x2 t = {0.f, 0.f};
+            if (valid) t = *reinterpret_cast<const f32x2 *>(x + ((size_t)(8 * h + j) * n + row) * 2);
+            P::set(k, 2 * j, t[0]);
+            P::set(k, 2 * j + 1, t[1]);
+        }
     }
     return k;
 }
@@ -225,8 +237,8 @@ __device__ __forceinline__ float sum16(const f32x16 &a) {
 
 // ---------------------------------------------------------------- forward
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t n, Weights w,
-                                                                     float *__restrict__ out) {
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, int x_planes, uint32_t n,
+                                                                     Weights w, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_FWD_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_FWD_COUNT);
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row = (size_t)tile * 32 + p;
         const bool valid = row < n;
-        const typename P::KB X = load_rows_kb<P>(x, row, valid, h);
+        const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
         typename P::KB H1[NTH], H2[NTH];
         uint32_t m;
 #pragma unroll
@@ -277,7 +289,7 @@ struct Grads {
 };
 
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x,
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x, int x_planes,
                                                                       const float *__restrict__ dout, uint32_t n,
                                                                       Weights w, float *__restrict__ dx, int dx_planes,
                                                                       Grads g) {
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row0 = (size_t)tile * 32, row = row0 + p;
         const bool valid = row < n;
-        const typename P::KB X = load_rows_kb<P>(x, row, valid, h);
+        const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
         const typename P::KB dO = load_dout_kb<P>(dout, row, valid, h);
 
         // ---- orientation 1 (lane = sample): recompute the activations and their ReLU masks
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const size_t r = row0 + rowmap(q, h);
-            P::set(Xp, q, r < n ? x[r * DIN + p] : 0.f);
+            P::set(Xp, q, r >= n ? 0.f : x_planes ? x[((size_t)(p >> 1) * n + r) * 2 + (p & 1)] : x[r * DIN + p]);
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
@@ -483,7 +495,7 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
     return dims_ok(dim_in, dim_hidden, dim_out, num_layers) ? 1 : 0;
 }
 
-int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+int mi3d_mlp_forward(const float *x, int x_planes, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream) {
     if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
@@ -491,14 +503,14 @@ int mi3d_mlp_forward(const float *x, uint32_t n, const float *W1, const float *b
     const Weights w{W1, b1, W2, b2, W3, b3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_forward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, n, w, out);
+                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_planes, n, w, out);
     else
         hipLaunchKernelGGL(k_mlp_forward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, n, w, out);
+                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_planes, n, w, out);
     return (int)hipGetLastError();
 }
 
-int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float *W1, const float *b1,
+int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
                       uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
                       float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream) {
@@ -508,10 +520,10 @@ int mi3d_mlp_backward(const float *x, const float *dout, uint32_t n, const float
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, dx_planes, g);
+                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, g);
     else
         hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, dout, n, w, dx, dx_planes, g);
+                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, g);
     return (int)hipGetLastError();
 }
 

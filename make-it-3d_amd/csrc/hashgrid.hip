@@ -110,6 +110,57 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
     }
 }
 
+// ---------------------------------------------------------------- forward, level-major planes, one level pair per XCD
+// rocprofv3 on the row kernel above (profiles/pmc_r01.json): 191 GB of FETCH_SIZE per launch against 145 GB of
+// algorithmic gather bytes - every XCD touches all 16 levels (48.8 MB) through a 4 MB L2, so the hashed levels miss and
+// each 8-byte gather pulls a line across the fabric.  Here workgroup b serves levels (b % 8) and (b % 8) + 8 ONLY - the
+// dispatcher places block b on XCD b % 8 - for ALL samples, one level at a time, so the tables an XCD gathers from are
+// one coarse level plus one 4 MB hashed level at any moment and stay L2-resident.  Output is level-major planes
+// [L][n*P][2] (what the MLP kernels read with x_planes != 0); a tile's 64 x P rows are contiguous in a plane and
+// leave through an LDS stage in full lines.
+constexpr uint32_t kXcds = 8;
+
+__global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
+                                                                       const float2 *__restrict__ table, GridTable T,
+                                                                       float2 *__restrict__ planes) {
+    __shared__ float2 stage_all[kWaves][kTile * kMaxPts];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    float2 *stage = stage_all[wave];
+    const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const size_t rows_total = (size_t)n * ps.P;
+    for (uint32_t l = xcd; l < T.n_levels; l += kXcds) {
+        const GridLevel L = T.level[l];
+        const float2 *lvl = table + L.offset;
+        float2 *plane = planes + (size_t)l * rows_total;
+        for (uint32_t tile = wg_in_xcd * kWaves + wave; tile < n_tiles; tile += wgs_per_xcd * kWaves) {
+            const uint32_t s = tile * kTile + lane;
+            const bool valid = s < n;
+            float base[2][3];
+            load_bases(ps, s, valid, base);
+            for (uint32_t p = 0; p < ps.P; ++p) {
+                float q[3];
+                point_of(ps, base, p, q);
+                float r0 = 0.f, r1 = 0.f;
+                if (valid) {
+                    Corners c;
+                    grid_corners(L, q[0], q[1], q[2], c);
+                    float2 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = lvl[c.idx[k]];  // 8 independent 8-byte gathers in flight
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { r0 += c.w[k] * v[k].x; r1 += c.w[k] * v[k].y; }
+                }
+                stage[lane * ps.P + p] = make_float2(r0, r1);
+            }
+            const uint32_t live = (n - tile * kTile < (uint32_t)kTile ? n - tile * kTile : (uint32_t)kTile) * ps.P;
+            float2 *dst = plane + (size_t)tile * kTile * ps.P;
+            for (uint32_t e = lane; e < live; e += kWave) dst[e] = stage[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward
 // One kernel, every level.  A QUAD of lanes serves one (sample, point, level): lane (dx, f) of the quad owns
 // feature f of the two corners x+dx, so the 4 dwords of an x-neighbour pair leave in ONE request.  A wave
@@ -713,6 +764,28 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
                        count, reinterpret_cast<const float2 *>(params), T, out);
     return (int)hipGetLastError();
 }
+
+int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                                   uint32_t P, float bound, const float *params, uint32_t n_levels,
+                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                                   float *out_planes, void *stream) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
+        (P0 < P && x2 == nullptr))
+        return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
+    const uint32_t tiles = (n + kTile - 1) / kTile;
+    uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
+    static const uint32_t per_cu = getenv("MI3D_ENCODE_WGS_PER_CU") ? (uint32_t)atoi(getenv("MI3D_ENCODE_WGS_PER_CU")) : 2u;  // measured: 2 -> 39.9 ms, 4 -> 43.0 ms at C2
+    const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU
+    per_xcd = per_xcd < cap ? per_xcd : cap;
+    hipLaunchKernelGGL(k_grid_encode_planes, dim3(per_xcd * kXcds), dim3(kWave * kWaves), 0, as_stream(stream), ps, n,
+                       reinterpret_cast<const float2 *>(params), T, reinterpret_cast<float2 *>(out_planes));
+    return (int)hipGetLastError();
+}
+
 
 int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
                              const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,

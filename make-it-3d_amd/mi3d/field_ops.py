@@ -83,16 +83,16 @@ class _FieldStencil(Function):
         ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
         offs, offs_p = grid_ops._offs_arg(offsets)
         P, n = offs.shape[0], x.shape[0]
-        F = cfg["n_levels"] * 2
-        feats = torch.empty(n * P, F, dtype=torch.float32, device=x.device)
+        # features as level-major planes [L][n*P][2]: written by the per-XCD gather, read as such by both MLP kernels
+        feats = torch.empty(cfg["n_levels"], n * P, 2, dtype=torch.float32, device=x.device)
         grid_ops._timed("encode", lambda: L.call(
-            "mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(None), offs_p, int(P0), P, float(bound),
-            L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"],
-            L.ptr(feats), L.stream()), n * P)
+            "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
+            cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(feats),
+            L.stream()), n * P)
         dims = (W1.shape[1], W1.shape[0], W3.shape[0])
         h = torch.empty(n * P, dims[2], dtype=torch.float32, device=x.device)
         grid_ops._timed("mlp_fwd", lambda: L.call(
-            "mi3d_mlp_forward", L.ptr(feats), n * P, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h),
+            "mi3d_mlp_forward", L.ptr(feats), 1, n * P, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h),
             L.stream()), n * P)
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, *ws)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
@@ -104,12 +104,12 @@ class _FieldStencil(Function):
     def backward(ctx, dh):
         x, x2, feats, *ws = ctx.saved_tensors
         offs, P0, bound, cfg, step, has_x2, n_params, dims, half_mode = ctx.meta
-        rows = feats.shape[0]
+        rows = feats.shape[1]
         dh = L.dev_f32(dh.float().contiguous(), "dh", dims[2])
         dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
         grads = [torch.zeros_like(t) for t in ws]
         grid_ops._timed("mlp_bwd", lambda: L.call(
-            "mi3d_mlp_backward", L.ptr(feats), L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, half_mode,
+            "mi3d_mlp_backward", L.ptr(feats), 1, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, half_mode,
             L.ptr(dplanes), 1, *[L.ptr(g) for g in grads], L.stream()), rows)
         gp = scatter_binned(x, x2 if has_x2 else None, offs, P0, bound, dplanes, cfg, step, n_params)
         return (gp, *grads, None, None, None, None, None, None, None, None)

@@ -22,7 +22,7 @@ class _FusedMLP(Function):
         out = torch.empty(n, W3.shape[0], dtype=torch.float32, device=x.device)
         dims = (W1.shape[1], W1.shape[0], W3.shape[0])
         grid_ops._timed("mlp_fwd", lambda: L.call(
-            "mi3d_mlp_forward", L.ptr(x), n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out), L.stream()), n)
+            "mi3d_mlp_forward", L.ptr(x), 0, n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out), L.stream()), n)
         ctx.save_for_backward(x, *ws)
         ctx.meta = (dims, int(half_mode))
         return out
@@ -37,7 +37,7 @@ class _FusedMLP(Function):
         dx = torch.empty_like(x)
         grads = [torch.zeros_like(t) for t in ws]
         grid_ops._timed("mlp_bwd", lambda: L.call(
-            "mi3d_mlp_backward", L.ptr(x), L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
+            "mi3d_mlp_backward", L.ptr(x), 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
             0, *[L.ptr(g) for g in grads], L.stream()), n)
         return (dx, *grads, None)
 
