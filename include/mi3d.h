@@ -180,6 +180,25 @@ int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t 
                       uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
                       float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream);
 
+/* ------------------------------------------------------------------ Part 5: the field head */
+
+/* From the MLP output h [n, P, 4] of the stencil points (P = 7: sample + its six +-epsilon neighbours in the order
+ * +x,-x,+y,-y,+z,-z; P = 13: plus the six neighbours of x2) to what the renderer consumes, in one elementwise pass:
+ *   sigma [n]     = exp(h_0[0] + blob(x))                         network_tcnn.py:94-100,109, activation.py:5-18
+ *   albedo [n,3]  = sigmoid(h_0[1..3])                            network_tcnn.py:110
+ *   normal [n,3]  = nan_to_num(safe_normalize(-(sigma+ - sigma-) / (2 epsilon)))   network_tcnn.py:115-138, utils.py:47-48
+ *   normal2 [n,3] = the same around x2 (P = 13 only)              nerf/renderer.py:521-524
+ * The stencil positions are clamp(base + offsets_host[p], -bound, bound), as in mi3d_grid_encode_points. */
+int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
+                            uint32_t P, float bound, float blob_density, float blob_radius, float epsilon, float *sigma,
+                            float *albedo, float *normal, float *normal2, void *stream);
+/* Backward: upstream gradients (any may be NULL = zero) -> dh [n, P, 4]; trunc_exp's clamped derivative
+ * (activation.py:15-18), clamp and nan_to_num pass gradients exactly where torch's do. */
+int mi3d_field_head_backward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
+                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon,
+                             const float *dsigma, const float *dalbedo, const float *dnormal, const float *dnormal2,
+                             float *dh, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

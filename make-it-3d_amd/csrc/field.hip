@@ -473,6 +473,138 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
     }
 }
 
+// ---------------------------------------------------------------- field head (elementwise, one thread per sample)
+// sigma, albedo and the two finite-difference normals from the MLP output of the P = 7 or 13 stencil points
+// (network_tcnn.py:94-138, activation.py:5-18, nerf/utils.py:47-48) in one pass instead of ~40 elementwise launches
+// over [n, P] tensors.  Point 0 is the sample, 1..6 its +-eps neighbours (+x,-x,+y,-y,+z,-z), 7..12 those of x2.
+struct HeadArgs {
+    const float *x, *x2;
+    float offs[MI3D_MAX_POINTS * 3];
+    uint32_t P;
+    float bound, blob_density, two_r2, inv_2eps;
+};
+
+__device__ __forceinline__ float head_gauss(const HeadArgs &a, const float *base, uint32_t p) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float v = fminf(a.bound, fmaxf(-a.bound, base[d] + a.offs[p * 3 + d]));
+        d2 += v * v;
+    }
+    return a.blob_density * expf(-d2 / a.two_r2);  // divide like torch does (network_tcnn.py:98)
+}
+
+// v / sqrt(clamp(|v|^2, 1e-20, 1e32)), NaN -> 0, +-inf -> +-FLT_MAX  (safe_normalize, then torch.nan_to_num)
+__device__ __forceinline__ void head_normal(const float s[6], float inv_2eps, float n[3], float v[3], float &c) {
+    v[0] = -((s[0] - s[1]) * inv_2eps); v[1] = -((s[2] - s[3]) * inv_2eps); v[2] = -((s[4] - s[5]) * inv_2eps);
+    const float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    c = fminf(1e32f, fmaxf(1e-20f, ss));
+    const float r = 1.0f / sqrtf(c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float t = v[d] * r;
+        if (t != t) t = 0.f;
+        else if (t > 3.4028234663852886e38f) t = 3.4028234663852886e38f;
+        else if (t < -3.4028234663852886e38f) t = -3.4028234663852886e38f;
+        n[d] = t;
+    }
+}
+
+__global__ void k_head_forward(const float4 *__restrict__ h, HeadArgs a, uint32_t n, float *__restrict__ sigma,
+                               float *__restrict__ albedo, float *__restrict__ normal, float *__restrict__ normal2) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float bx[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
+    const float4 h0 = h[(size_t)s * a.P];
+    sigma[s] = expf(h0.x + head_gauss(a, bx, 0));
+    albedo[(size_t)s * 3] = 1.0f / (1.0f + expf(-h0.y));
+    albedo[(size_t)s * 3 + 1] = 1.0f / (1.0f + expf(-h0.z));
+    albedo[(size_t)s * 3 + 2] = 1.0f / (1.0f + expf(-h0.w));
+    float sg[6], nn[3], v[3], c;
+#pragma unroll
+    for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)s * a.P + 1 + p].x + head_gauss(a, bx, 1 + p));
+    head_normal(sg, a.inv_2eps, nn, v, c);
+    normal[(size_t)s * 3] = nn[0]; normal[(size_t)s * 3 + 1] = nn[1]; normal[(size_t)s * 3 + 2] = nn[2];
+    if (a.P == 13) {
+        float b2[3] = {a.x2[(size_t)s * 3], a.x2[(size_t)s * 3 + 1], a.x2[(size_t)s * 3 + 2]};
+#pragma unroll
+        for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)s * a.P + 7 + p].x + head_gauss(a, b2, 7 + p));
+        head_normal(sg, a.inv_2eps, nn, v, c);
+        normal2[(size_t)s * 3] = nn[0]; normal2[(size_t)s * 3 + 1] = nn[1]; normal2[(size_t)s * 3 + 2] = nn[2];
+    }
+}
+
+// gradient of one normal wrt the six pre-activations u_p = h_p0 + gauss_p (sigma_p = exp(u_p), trunc_exp backward
+// evaluates exp at min(u_p, 15)); dn is the upstream gradient of the (nan_to_num'ed) normal
+__device__ __forceinline__ void head_normal_backward(const float u[6], float inv_2eps, const float dn_in[3], float du[6]) {
+    float sg[6], nn[3], v[3], c;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) sg[p] = expf(u[p]);
+    head_normal(sg, inv_2eps, nn, v, c);
+    const float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float r = 1.0f / sqrtf(c);
+    float dn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // nan_to_num passes the gradient where its input is finite
+        const float t = v[d] * r;
+        dn[d] = (t == t && fabsf(t) <= 3.4028234663852886e38f) ? dn_in[d] : 0.f;
+    }
+    const float dot = dn[0] * v[0] + dn[1] * v[1] + dn[2] * v[2];
+    const bool inside = ss >= 1e-20f && ss <= 1e32f;  // clamp passes the gradient inside its range
+    const float k = inside ? dot * (r / c) : 0.f;      // d(1/sqrt(c))/d(ss) * 2 v = -c^-1.5 v
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float dv = r * dn[d] - k * v[d];
+        const float dg = -dv * inv_2eps;  // v = -(s+ - s-) * inv_2eps
+        du[2 * d] = dg * expf(fminf(u[2 * d], 15.0f));
+        du[2 * d + 1] = -dg * expf(fminf(u[2 * d + 1], 15.0f));
+    }
+}
+
+__global__ void k_head_backward(const float4 *__restrict__ h, HeadArgs a, uint32_t n, const float *__restrict__ dsigma,
+                                const float *__restrict__ dalbedo, const float *__restrict__ dnormal,
+                                const float *__restrict__ dnormal2, float4 *__restrict__ dh) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float bx[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
+    const float4 h0 = h[(size_t)s * a.P];
+    float4 g0;
+    g0.x = (dsigma ? dsigma[s] : 0.f) * expf(fminf(h0.x + head_gauss(a, bx, 0), 15.0f));
+    const float a0 = 1.0f / (1.0f + expf(-h0.y)), a1 = 1.0f / (1.0f + expf(-h0.z)), a2 = 1.0f / (1.0f + expf(-h0.w));
+    g0.y = dalbedo ? dalbedo[(size_t)s * 3] * a0 * (1.0f - a0) : 0.f;
+    g0.z = dalbedo ? dalbedo[(size_t)s * 3 + 1] * a1 * (1.0f - a1) : 0.f;
+    g0.w = dalbedo ? dalbedo[(size_t)s * 3 + 2] * a2 * (1.0f - a2) : 0.f;
+    dh[(size_t)s * a.P] = g0;
+    float u[6], du[6], dn[3];
+#pragma unroll
+    for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)s * a.P + 1 + p].x + head_gauss(a, bx, 1 + p);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dn[d] = dnormal ? dnormal[(size_t)s * 3 + d] : 0.f;
+    head_normal_backward(u, a.inv_2eps, dn, du);
+#pragma unroll
+    for (uint32_t p = 0; p < 6; ++p) dh[(size_t)s * a.P + 1 + p] = make_float4(du[p], 0.f, 0.f, 0.f);
+    if (a.P == 13) {
+        float b2[3] = {a.x2[(size_t)s * 3], a.x2[(size_t)s * 3 + 1], a.x2[(size_t)s * 3 + 2]};
+#pragma unroll
+        for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)s * a.P + 7 + p].x + head_gauss(a, b2, 7 + p);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dn[d] = dnormal2 ? dnormal2[(size_t)s * 3 + d] : 0.f;
+        head_normal_backward(u, a.inv_2eps, dn, du);
+#pragma unroll
+        for (uint32_t p = 0; p < 6; ++p) dh[(size_t)s * a.P + 7 + p] = make_float4(du[p], 0.f, 0.f, 0.f);
+    }
+}
+
+HeadArgs make_head_args(const float *x, const float *x2, const float *offsets_host, uint32_t P, float bound,
+                        float blob_density, float blob_radius, float epsilon) {
+    HeadArgs a;
+    a.x = x; a.x2 = x2; a.P = P; a.bound = bound; a.blob_density = blob_density;
+    a.two_r2 = (float)(2.0 * (double)blob_radius * (double)blob_radius);
+    a.inv_2eps = 0.5f / epsilon;
+    for (uint32_t i = 0; i < MI3D_MAX_POINTS * 3; ++i) a.offs[i] = i < P * 3 ? offsets_host[i] : 0.f;
+    return a;
+}
+
 template <class P> constexpr size_t lds_bytes(int n_blocks) {
     return (size_t)n_blocks * block_bytes<P>() + (HID + HID + 32) * sizeof(float);
 }
@@ -526,5 +658,30 @@ int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t 
                            lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, g);
     return (int)hipGetLastError();
 }
+
+int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
+                            uint32_t P, float bound, float blob_density, float blob_radius, float epsilon, float *sigma,
+                            float *albedo, float *normal, float *normal2, void *stream) {
+    if ((P != 7 && P != 13) || (P == 13 && (x2 == nullptr || normal2 == nullptr))) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    const HeadArgs a = make_head_args(x, x2, offsets_host, P, bound, blob_density, blob_radius, epsilon);
+    hipLaunchKernelGGL(k_head_forward, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(h), a, n, sigma, albedo, normal, normal2);
+    return (int)hipGetLastError();
+}
+
+int mi3d_field_head_backward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
+                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon,
+                             const float *dsigma, const float *dalbedo, const float *dnormal, const float *dnormal2,
+                             float *dh, void *stream) {
+    if ((P != 7 && P != 13) || (P == 13 && x2 == nullptr)) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    const HeadArgs a = make_head_args(x, x2, offsets_host, P, bound, blob_density, blob_radius, epsilon);
+    hipLaunchKernelGGL(k_head_backward, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(h), a, n, dsigma, dalbedo, dnormal, dnormal2,
+                       reinterpret_cast<float4 *>(dh));
+    return (int)hipGetLastError();
+}
+
 
 }  // extern "C"

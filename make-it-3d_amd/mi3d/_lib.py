@@ -44,6 +44,9 @@ _SIGNATURES = {
     "mi3d_mlp_supported": [u32, u32, u32, u32],
     "mi3d_mlp_forward": [vp, i32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
     "mi3d_mlp_backward": [vp, i32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    # Part 5 ------------------------------------------------------------------------------------------
+    "mi3d_field_head_forward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
 }
 
 

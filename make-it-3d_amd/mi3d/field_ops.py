@@ -126,3 +126,53 @@ def field_stencil(params, layers, x, offsets, cfg, bound=1.0, x2=None, P0=None, 
     l1, l2, l3 = layers
     return _FieldStencil.apply(params, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, x, x2, offsets, P0,
                                bound, cfg, step, bool(half_mode))
+
+
+class _FieldHead(Function):
+    """sigma, albedo, normal(x), normal(x2) from h [n*P, 4] in one elementwise kernel per direction (C ABI Part 5)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, h, x, x2, offsets, bound, blob_density, blob_radius, epsilon):
+        offs, offs_p = grid_ops._offs_arg(offsets)
+        P = offs.shape[0]
+        x = L.dev_f32(x.contiguous().view(-1, 3), "x", 3)
+        n = x.shape[0]
+        h = L.dev_f32(h.contiguous().view(n * P, 4), "h", 4)
+        if x2 is not None:
+            x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
+        dev = x.device
+        sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        albedo = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        normal = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        normal2 = torch.empty(n, 3, dtype=torch.float32, device=dev) if P == 13 else None
+        grid_ops._timed("head_fwd", lambda: L.call(
+            "mi3d_field_head_forward", L.ptr(h), L.ptr(x), L.ptr(x2), n, offs_p, P, float(bound), float(blob_density),
+            float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal), L.ptr(normal2),
+            L.stream()), n)
+        ctx.save_for_backward(h, x, x2 if x2 is not None else x)
+        ctx.meta = (offs, P, float(bound), float(blob_density), float(blob_radius), float(epsilon), x2 is not None)
+        if normal2 is None:
+            return sigma, albedo, normal
+        return sigma, albedo, normal, normal2
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, *grads):
+        h, x, x2 = ctx.saved_tensors
+        offs, P, bound, blob_density, blob_radius, epsilon, has_x2 = ctx.meta
+        _, offs_p = grid_ops._offs_arg(offs)
+        g = [None if t is None else L.dev_f32(t.float().contiguous(), "grad") for t in grads] + [None]
+        dh = torch.empty_like(h)
+        n = x.shape[0]
+        grid_ops._timed("head_bwd", lambda: L.call(
+            "mi3d_field_head_backward", L.ptr(h), L.ptr(x), L.ptr(x2 if has_x2 else None), n, offs_p, P, bound,
+            blob_density, blob_radius, epsilon, L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]), L.ptr(dh),
+            L.stream()), n)
+        return dh, None, None, None, None, None, None, None
+
+
+def field_head(h, x, offsets, bound, blob_density, blob_radius, x2=None, epsilon=grid_ops.EPS):
+    """(sigma [n], albedo [n,3], normal [n,3], normal_jitter [n,3] or None) from h [n*P, 4]; P must be 7 or 13."""
+    out = _FieldHead.apply(h, x, x2, offsets, bound, blob_density, blob_radius, epsilon)
+    return out if len(out) == 4 else (*out, None)

@@ -142,6 +142,11 @@ class NeRFNetwork(NeRFRenderer):
     def field_stencil(self, x, x2=None, step=0.0):
         x = x.reshape(-1, 3).float()
         offs, P0 = grid_ops.stencil_offsets(center=True, second=x2 is not None)
+        if x.is_cuda and self.sigma_net.fused_ok(x) and self.encoder.cfg["n_levels"] * 2 == self.sigma_net.dim_in:
+            # one node for encode + MLP, one for the whole head (sigma, albedo, both finite-difference normals)
+            h = field_ops.field_stencil(self.encoder.params, self.sigma_net.net, x, offs, self.encoder.cfg,
+                                        float(self.bound), x2, P0 if x2 is not None else None, step)
+            return field_ops.field_head(h, x, offs, float(self.bound), self.opt.blob_density, self.opt.blob_radius, x2)
         sig, h = self._stencil_sigma(x, offs, x2, P0 if x2 is not None else None, step)
         albedo = torch.sigmoid(h[:, 0, 1:])
         normals = self._normal_from(sig[:, 1:7])
