@@ -38,6 +38,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using ushort8v = __attribute__((ext_vector_type(8))) unsigned short;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -64,6 +66,46 @@ struct F16 {
         k.v[1] = *reinterpret_cast<const half8 *>(blk + (1 * kWave + lane) * 16);
         return k;
     }
+    // accumulator tile -> ReLU'd K-block: packed convert (the layer output is rounded to binary16 first, as autocast
+    // does), packed max.  The K-block itself is the ReLU mask later on (value > 0 <=> bits != 0).
+    __device__ static __forceinline__ KB relu(const f32x16 &acc) {
+        KB k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 pr = {acc[2 * j], acc[2 * j + 1]};
+            half2v hv = __builtin_convertvector(pr, half2v);
+            hv = __builtin_elementwise_max(hv, half2v{(_Float16)0, (_Float16)0});
+            k.v[j >> 2][2 * (j & 3)] = hv[0];
+            k.v[j >> 2][2 * (j & 3) + 1] = hv[1];
+        }
+        return k;
+    }
+    // gradient tile masked by the ReLU of `act` (a K-block from relu()): convert, AND with 0xFFFF where act != 0
+    __device__ static __forceinline__ KB masked(const f32x16 &d, const KB &act) {
+        KB k;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            half8 hv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hv[i] = (_Float16)d[8 * u + i];
+            const ushort8v bits = __builtin_bit_cast(ushort8v, act.v[u]);
+            const ushort8v one = {1, 1, 1, 1, 1, 1, 1, 1};
+            const ushort8v m = (ushort8v)(0) - __builtin_elementwise_min(bits, one);  // 0xFFFF where act != 0
+            k.v[u] = __builtin_bit_cast(half8, (ushort8v)(__builtin_bit_cast(ushort8v, hv) & m));
+        }
+        return k;
+    }
+    // fp32 sum of the 16 values of a K-block (v_dot2_f32_f16 against ones)
+    __device__ static __forceinline__ float sum(const KB &k) {
+        float s = 0.f;
+        const half2v ones = {(_Float16)1, (_Float16)1};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half2v pr = {k.v[j >> 2][2 * (j & 3)], k.v[j >> 2][2 * (j & 3) + 1]};
+            s = __builtin_amdgcn_fdot2(pr, ones, s, false);
+        }
+        return s;
+    }
 };
 
 struct F32 {
@@ -88,6 +130,24 @@ struct F32 {
             k.v[4 * u] = t[0]; k.v[4 * u + 1] = t[1]; k.v[4 * u + 2] = t[2]; k.v[4 * u + 3] = t[3];
         }
         return k;
+    }
+    __device__ static __forceinline__ KB relu(const f32x16 &acc) {
+        KB k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) k.v[q] = fmaxf(acc[q], 0.f);
+        return k;
+    }
+    __device__ static __forceinline__ KB masked(const f32x16 &d, const KB &act) {
+        KB k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) k.v[q] = act.v[q] > 0.f ? d[q] : 0.f;
+        return k;
+    }
+    __device__ static __forceinline__ float sum(const KB &k) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += k.v[q];
+        return s;
     }
 };
 
@@ -191,30 +251,6 @@ __device__ __forceinline__ typename P::KB load_dout_kb(const float *__restrict__
     return k;
 }
 
-// accumulator tile -> K-block (kind D) with ReLU; also returns the >0 mask (bit q)
-template <class P>
-__device__ __forceinline__ typename P::KB relu_kb(const f32x16 &acc, uint32_t &mask) {
-    typename P::KB k;
-    mask = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float v = P::round(acc[q]);  // the layer output is rounded first (autocast), then ReLU
-        const bool on = v > 0.f;
-        mask |= on ? (1u << q) : 0u;
-        P::set(k, q, on ? v : 0.f);
-    }
-    return k;
-}
-template <class P>
-__device__ __forceinline__ typename P::KB masked_kb(f32x16 &acc, uint32_t mask) {
-    typename P::KB k;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        acc[q] = ((mask >> q) & 1u) ? acc[q] : 0.f;
-        P::set(k, q, acc[q]);
-    }
-    return k;
-}
 __device__ __forceinline__ f32x16 splat(float v) {
     f32x16 a;
 #pragma unroll
@@ -228,13 +264,6 @@ __device__ __forceinline__ f32x16 bias_rows(const float *bias, int h) {
     for (int q = 0; q < 16; ++q) a[q] = bias[rowmap(q, h)];
     return a;
 }
-__device__ __forceinline__ float sum16(const f32x16 &a) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) s += a[q];
-    return s;
-}
-
 // ---------------------------------------------------------------- forward
 template <class P>
 __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, int x_planes, uint32_t n,
@@ -259,19 +288,18 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float 
         const bool valid = row < n;
         const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
         typename P::KB H1[NTH], H2[NTH];
-        uint32_t m;
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = bias_rows(bias + 32 * t, h);
             P::mma(acc, blk(B_W1 + t), X);
-            H1[t] = relu_kb<P>(acc, m);
+            H1[t] = P::relu(acc);
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = bias_rows(bias + HID + 32 * t, h);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2 + t * NTH + tk), H1[tk]);
-            H2[t] = relu_kb<P>(acc, m);
+            H2[t] = P::relu(acc);
         }
         f32x16 acc = bias_rows(bias + 2 * HID, h);
 #pragma unroll
@@ -324,21 +352,20 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
         const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
         const typename P::KB dO = load_dout_kb<P>(dout, row, valid, h);
 
-        // ---- orientation 1 (lane = sample): recompute the activations and their ReLU masks
+        // ---- orientation 1 (lane = sample): recompute the activations (they double as their own ReLU masks)
         typename P::KB H1[NTH], H2[NTH];
-        uint32_t m1[NTH], m2[NTH];
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = bias_rows(bias + 32 * t, h);
             P::mma(acc, blk(B_W1 + t), X);
-            H1[t] = relu_kb<P>(acc, m1[t]);
+            H1[t] = P::relu(acc);
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = bias_rows(bias + HID + 32 * t, h);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2 + t * NTH + tk), H1[tk]);
-            H2[t] = relu_kb<P>(acc, m2[t]);
+            H2[t] = P::relu(acc);
         }
         // ---- orientation 1: input-side gradients  dH2 = W3^T dO, dH1 = W2^T dH2, dX = W1^T dH1
         typename P::KB dH2[NTH], dH1[NTH];
@@ -346,14 +373,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = splat(0.f);
             P::mma_lo(acc, blk(B_W3T + t), dO);
-            dH2[t] = masked_kb<P>(acc, m2[t]);
+            dH2[t] = P::masked(acc, H2[t]);
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = splat(0.f);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2T + t * NTH + tk), dH2[tk]);
-            dH1[t] = masked_kb<P>(acc, m1[t]);
+            dH1[t] = P::masked(acc, H1[t]);
         }
         {
             f32x16 acc = splat(0.f);
@@ -386,9 +413,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = splat(bias[32 * t + p]);
             P::mma(acc, X, blk(B_W1 + t));
-            uint32_t m;
-            H1p[t] = relu_kb<P>(acc, m);
-            m1[t] = m;  // from here on m1 holds the orientation-2 mask (orientation-1 masks are consumed)
+            H1p[t] = P::relu(acc);
         }
         // dO with lane = output index, values = samples (A operand of dW3); its sum over samples is db3
         typename P::KB dOp;
@@ -405,13 +430,12 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
             f32x16 acc = splat(bias[HID + 32 * t + p]);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(acc, H1[tk], blk(B_W2 + t * NTH + tk));
-            uint32_t m;
-            const typename P::KB H2p = relu_kb<P>(acc, m);
+            const typename P::KB H2p = P::relu(acc);
             P::mma(gW3[t], dOp, H2p);  // dW3[o][f] += sum_s dO[s][o] H2[s][f]
             f32x16 d = splat(0.f);
             P::mma_lo(d, dO, blk(B_W3T + t));
-            dH2p[t] = masked_kb<P>(d, m);
-            gb2[t] += sum16(d);
+            dH2p[t] = P::masked(d, H2p);
+            gb2[t] += P::sum(dH2p[t]);
         }
         // dW2[i][j] += sum_s dH2[s][i] H1[s][j]
 #pragma unroll
@@ -430,8 +454,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
             f32x16 d = splat(0.f);
 #pragma unroll
             for (int tk = 0; tk < NTH; ++tk) P::mma(d, dH2[tk], blk(B_W2T + t * NTH + tk));
-            const typename P::KB dH1p = masked_kb<P>(d, m1[t]);
-            gb1[t] += sum16(d);
+            const typename P::KB dH1p = P::masked(d, H1p[t]);
+            gb1[t] += P::sum(dH1p);
             P::mma(gW1[t], dH1p, Xp);
         }
     }

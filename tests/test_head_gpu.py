@@ -54,8 +54,9 @@ def test_head_matches_torch_composition(cuda, second):
     want = _torch_head(href, x, x2, offs, 1.0, 5.0, 0.1)
     assert len(got) == len(want)
     for a, b, name in zip(got, want, ["sigma", "albedo", "normal", "normal2"]):
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6,
-                                   err_msg=name)
+        # normals are ratios of differences of nearly equal exponentials: 1 ulp of expf moves them by ~1e-5
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5,
+                                   atol=5e-5 if name.startswith("normal") else 2e-6, err_msg=name)
     gs = [torch.randn_like(t) for t in want]
     torch.autograd.backward(got, gs)
     torch.autograd.backward(want, gs)
