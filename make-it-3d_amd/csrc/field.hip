@@ -320,7 +320,7 @@ template <class P>
 __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x, int x_planes,
                                                                       const float *__restrict__ dout, uint32_t n,
                                                                       Weights w, float *__restrict__ dx, int dx_planes,
-                                                                      Grads g) {
+                                                                      float *__restrict__ level_absmax, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_ALL_COUNT);
@@ -345,6 +345,10 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
 #pragma unroll
         for (int b = 0; b < NTH; ++b) gW2[a][b] = splat(0.f);
     }
+
+    float lvmax[8];  // planes mode: largest |dx| per level this lane wrote (levels 4c + 2h + u at index 2c + u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lvmax[j] = 0.f;
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row0 = (size_t)tile * 32, row = row0 + p;
@@ -399,6 +403,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     f32x2 a = {acc[4 * c], acc[4 * c + 1]}, b = {acc[4 * c + 2], acc[4 * c + 3]};
+                    lvmax[2 * c] = fmaxf(lvmax[2 * c], fmaxf(fabsf(a[0]), fabsf(a[1])));
+                    lvmax[2 * c + 1] = fmaxf(lvmax[2 * c + 1], fmaxf(fabsf(b[0]), fabsf(b[1])));
                     const size_t lvl = 4 * c + 2 * h;
                     __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * n + row) * 2));
                     __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * n + row) * 2));
@@ -460,6 +466,18 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
         }
     }
 
+    // ---- per-level |dx| maxima (the binned scatter's 8-byte records are scaled by them): lanes of one half hold the
+    // same eight levels; non-negative floats order like their bit patterns
+    if (dx_planes && level_absmax != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = lvmax[j];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if (p == 0 && m > 0.f)
+                atomicMax(reinterpret_cast<unsigned int *>(level_absmax) + 4 * (j >> 1) + 2 * h + (j & 1), __float_as_uint(m));
+        }
+    }
     // ---- reduce the weight gradients across the workgroup in LDS, then one atomic per element per workgroup
     __syncthreads();
     float *red = reinterpret_cast<float *>(lds);
@@ -668,18 +686,19 @@ int mi3d_mlp_forward(const float *x, int x_planes, uint32_t n, const float *W1, 
 
 int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes, float *dW1,
-                      float *db1, float *dW2, float *db2, float *dW3, float *db3, void *stream) {
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes,
+                      float *level_absmax, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
+                      void *stream) {
     if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, g);
+                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, level_absmax, g);
     else
         hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, g);
+                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, level_absmax, g);
     return (int)hipGetLastError();
 }
 

@@ -44,9 +44,11 @@ def scatter_workspace(device, needed, budget_fraction=0.5):
     return _WORKSPACE[idx]
 
 
-def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None):
+def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None, level_absmax=None):
     """grad_params [n_params] from level-major feature-gradient planes [L][n*P][2] (C ABI: mi3d_grid_scatter_binned).
-    workspace_bytes: None = cached scratch sized by scatter_workspace; 0 = force the all-atomic path."""
+    workspace_bytes: None = cached scratch sized by scatter_workspace; 0 = force the all-atomic path.
+    level_absmax: float32[16] device tensor of per-level max |dplanes| (from the MLP backward) - selects the 8-byte
+    binary16 records for the fine levels; None keeps fp32 records everywhere."""
     offs, offs_p = grid_ops._offs_arg(offsets)
     P, n = offs.shape[0], x.shape[0]
     dplanes = L.dev_f32(dplanes, "dplanes")
@@ -58,7 +60,7 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     if workspace_bytes != 0 and n > 0:
         needed = lib.mi3d_grid_scatter_binned_workspace(n, P, float(bound), float(step), cfg["n_levels"],
                                                         cfg["base_resolution"], cfg["per_level_scale"],
-                                                        cfg["log2_hashmap_size"])
+                                                        cfg["log2_hashmap_size"], 1 if level_absmax is not None else 0)
         if workspace_bytes is not None:
             needed = min(needed, int(workspace_bytes))
             ws = torch.empty(needed, dtype=torch.uint8, device=x.device) if needed else None
@@ -68,7 +70,7 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     grid_ops._timed("scatter", lambda: L.call(
         "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
         cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-        L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream()), n * P)
+        L.ptr(level_absmax), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream()), n * P)
     return grad
 
 
@@ -108,10 +110,14 @@ class _FieldStencil(Function):
         dh = L.dev_f32(dh.float().contiguous(), "dh", dims[2])
         dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
         grads = [torch.zeros_like(t) for t in ws]
+        # under autocast the feature gradients are binary16-precise: the scatter may then use its 8-byte records,
+        # scaled per level by the maxima the MLP backward collects
+        absmax = torch.zeros(cfg["n_levels"], dtype=torch.float32, device=x.device) if half_mode else None
         grid_ops._timed("mlp_bwd", lambda: L.call(
             "mi3d_mlp_backward", L.ptr(feats), 1, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, half_mode,
-            L.ptr(dplanes), 1, *[L.ptr(g) for g in grads], L.stream()), rows)
-        gp = scatter_binned(x, x2 if has_x2 else None, offs, P0, bound, dplanes, cfg, step, n_params)
+            L.ptr(dplanes), 1, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream()), rows)
+        gp = scatter_binned(x, x2 if has_x2 else None, offs, P0, bound, dplanes, cfg, step, n_params,
+                            level_absmax=absmax)
         return (gp, *grads, None, None, None, None, None, None, None, None)
 
 

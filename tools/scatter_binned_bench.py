@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--bitfield", default="dense")
     ap.add_argument("--ws-gb", type=float, default=-1)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--half", action="store_true", help="8-byte binary16 records on the fine levels")
     a = ap.parse_args()
     import raymarching
     from mi3d import rays as R, grid_ops, field_ops, sds_step, network
@@ -33,11 +34,12 @@ def main():
     P = offs.shape[0]
     planes = torch.randn(16, m * P, 2, device=dev)
     ws = None if a.ws_gb < 0 else int(a.ws_gb * (1 << 30))
+    absmax = planes.abs().amax(dim=(1, 2)).contiguous() if a.half else None
     for i in range(a.iters):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        g = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, planes, cfg, 2 * 3 ** 0.5 / 1024, 12196240, workspace_bytes=ws)
+        g = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, planes, cfg, 2 * 3 ** 0.5 / 1024, 12196240, workspace_bytes=ws, level_absmax=absmax)
         torch.cuda.synchronize()
-        print(f"iter {i}: {1e3 * (time.perf_counter() - t0):.1f} ms  (m={m}, |g|={float(g.abs().sum()):.3e})")
+        print(f"iter {i}: {1e3 * (time.perf_counter() - t0):.1f} ms  (m={m}, |g|={float(g.abs().sum()):.3e})", flush=True)
 
 
 if __name__ == "__main__":
