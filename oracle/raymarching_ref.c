@@ -7,6 +7,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; the product path (make-it-3d_amd/) never does.
  *
+ * PINNED: tests/test_reference_kernels_gpu.py runs the reference's own kernels
+ * (the .cu above built for gfx950 by oracle/build_ref.py into oracle/_ref/) next
+ * to this restatement on an MI355X - integer kernels and near/far bit-exact,
+ * training march per-ray counts equal on every ray and sampled rays bit-exact,
+ * composite forward/backward and the inference loop within 1e-5.
+ *
  * Floating-point policy (DESIGN.md "FMA policy"): nvcc's default -fmad=true
  * contracts a*b+c into one fused multiply-add.  Every site where that
  * contraction changes an integer decision (sample position -> voxel index,
