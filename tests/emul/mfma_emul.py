@@ -49,13 +49,13 @@ def mfma_32x32x2(a, b, c):
 def kphys_f16(layer, s, h, e):
     """physical input index feeding logical K-slot (s,h,e) of an f16 layer"""
     if layer == 0:
-        return 16 * s + 8 * h + e                      # feature index (LDS row is read as 8 consecutive halfs)
-    return 32 * (s >> 1) + row_of(8 * (s & 1) + e, h)  # neuron held in acc[s>>1][8*(s&1)+e] of this lane
+        return 16 * h + 8 * s + e                      # kind X of field.hip: lane-half h holds features 16h .. 16h+15
+    return 32 * (s >> 1) + row_of(8 * (s & 1) + e, h)  # kind D: neuron held in acc[s>>1][8*(s&1)+e] of this lane
 
 
 def kphys_f32(layer, s, h):
     if layer == 0:
-        return 2 * s + h
+        return 16 * h + s if s < 16 else 32 + 16 * h + (s - 16)   # kind X, one value per step
     return 32 * (s >> 4) + row_of(s & 15, h)
 
 
@@ -136,9 +136,9 @@ def ref_mlp(feat, Ws, Bs):
     return h
 
 
-if __name__ == "__main__":
-    rng = np.random.default_rng(0)
-    for (F, H, NL) in [(32, 64, 3), (8, 32, 2)]:
+def check(seed=0):
+    rng = np.random.default_rng(seed)
+    for (F, H, NL) in [(32, 64, 3), (32, 32, 2)]:
         dims = [F] + [H] * (NL - 1) + [4]
         Ws = [rng.normal(size=(dims[i + 1], dims[i])) for i in range(NL)]
         Bs = [rng.normal(size=dims[i + 1]) for i in range(NL)]
@@ -146,6 +146,10 @@ if __name__ == "__main__":
         ref = ref_mlp(feat, Ws, Bs)
         e16 = np.abs(mlp_f16(feat, Ws, Bs) - ref).max()
         e32 = np.abs(mlp_f32(feat, Ws, Bs) - ref).max()
-        print(F, H, NL, "f16-path err", e16, "f32-path err", e32)
-        assert e16 < 1e-9 and e32 < 1e-9
+        assert e16 < 1e-9 and e32 < 1e-9, (F, H, NL, e16, e32)
+    return True
+
+
+if __name__ == "__main__":
+    check()
     print("MFMA chaining index math OK")
