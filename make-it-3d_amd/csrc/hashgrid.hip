@@ -417,7 +417,11 @@ struct __attribute__((aligned(8))) BinRecord16 {
     uint32_t entry;
     uint32_t g;  // binary16 pair (g0 | g1 << 16), pre-scaled by the level's power of two
 };
-constexpr uint32_t kChunk = 16, kRing = 32;  // records per staged flush (16 x 8 B = one 128-byte line), ring per bin
+#ifndef MI3D_EMIT16_CHUNK
+#define MI3D_EMIT16_CHUNK 16
+#endif
+// records per staged flush (16 x 8 B = one 128-byte line) and ring per bin (two chunks)
+constexpr uint32_t kChunk = MI3D_EMIT16_CHUNK, kRing = 2 * kChunk, kChunkLanes = kChunk / 2;
 constexpr size_t kEmit16LdsBytes = (size_t)4 * 64 * kRing * 8 + (size_t)4 * 256 * 4;  // kWaves = 4
 
 struct BinPlan {
@@ -700,10 +704,10 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint3
                 const uint32_t nr = (uint32_t)__popcll(ready);
                 if (rdy) list[__popcll(ready & lt)] = (uint32_t)lane;
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t j0 = 0; j0 < nr; j0 += 8) {
-                    const uint32_t j = j0 + ((uint32_t)lane >> 3);
+                for (uint32_t j0 = 0; j0 < nr; j0 += kWave / kChunkLanes) {
+                    const uint32_t j = j0 + (uint32_t)lane / kChunkLanes;
                     if (j < nr) {
-                        const uint32_t b = list[j], f = fl[b], part = (uint32_t)lane & 7u;
+                        const uint32_t b = list[j], f = fl[b], part = (uint32_t)lane % kChunkLanes;
                         const uint4 v = *reinterpret_cast<const uint4 *>(&stage[b * kRing + (f & 1u) * kChunk + part * 2]);
                         if ((f + 1) * kChunk <= cap) {
                             *reinterpret_cast<uint4 *>(rbase + (size_t)b * cap + f * kChunk + part * 2) = v;

@@ -10,7 +10,7 @@ import os
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libmi3d.so")
+LIB_PATH = os.environ.get("MI3D_LIB", os.path.join(_CSRC, "libmi3d.so"))  # MI3D_LIB: development builds only
 
 _lib = None
 
