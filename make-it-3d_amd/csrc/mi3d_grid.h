@@ -66,46 +66,18 @@ __device__ __forceinline__ void grid_corners(const GridLevel &L, float x, float 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scatter with wave64 run-merging.
+// Run merging in the scatter kernels.
 //
-// Neighbouring lanes hold neighbouring samples of one ray, so at the coarse and middle levels long runs of
-// lanes fall into the SAME lattice cell and would fire 16 fp32 atomics each at the same 16 addresses - the L2
-// atomic units serialise those (measured: 206 ms for one 10.9 M-sample backward without merging).  Lanes are
-// grouped into runs of equal cell key; a segmented inclusive scan (6 DPP steps) sums the 16 corner values over
-// each run and only the run's LAST lane issues atomics.  Any partition into equal-key runs is valid, so inactive
-// lanes simply break runs.
+// Neighbouring lanes hold neighbouring samples of one ray, so at the coarse and middle levels long runs of lanes
+// fall into the SAME lattice cell and would send their corner values to the same addresses (measured: 206 ms for one
+// 10.9 M-sample backward without merging).  The kernels in hashgrid.hip group lanes into runs of equal cell key and
+// sum each run before it leaves the wave - by a segmented scan across quads (k_scatter) or through an LDS slab
+// (k_scatter_runs, k_bin_emit).  Any partition into equal-key runs is valid, so inactive lanes simply break runs.
 struct CellKey {
     uint32_t a, b, c;  // lattice cell (cx, cy, cz)
 };
 __device__ __forceinline__ bool operator==(const CellKey &p, const CellKey &q) {
     return p.a == q.a && p.b == q.b && p.c == q.c;
-}
-
-template <int NV>
-__device__ __forceinline__ bool wave_merge_runs(bool active, CellKey key, float (&v)[NV], int lane) {
-    CellKey prev;
-    prev.a = __shfl_up(key.a, 1, 64);
-    prev.b = __shfl_up(key.b, 1, 64);
-    prev.c = __shfl_up(key.c, 1, 64);
-    const bool prev_active = __shfl_up((int)active, 1, 64) != 0;
-    const bool joins_prev = active && prev_active && lane > 0 && (key == prev);
-    const unsigned long long joins = __ballot(joins_prev);
-    if (joins != 0ull) {  // wave-uniform: skip the scan when no two neighbours share a cell (fine levels)
-        bool head = !joins_prev;  // a head lane never accumulates from below
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const bool up_head = __shfl_up((int)head, off, 64) != 0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const float up = __shfl_up(v[i], off, 64);
-                if (!head && lane >= off) v[i] += up;
-            }
-            head = head || (lane < off) || up_head;
-        }
-    }
-    // the last lane of each run owns the merged sums
-    const bool next_joins = (lane < 63) && (((joins >> (lane + 1)) & 1ull) != 0ull);
-    return active && !next_joins;
 }
 
 }  // namespace mi3d
