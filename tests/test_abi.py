@@ -59,3 +59,17 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) or "liboracle" in s:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_scatter_workspace_query_is_host_only_and_sane():
+    """mi3d_grid_scatter_binned_workspace is pure host arithmetic (no GPU): monotone in the sample count, smaller with
+    8-byte records, and at least the bytes of the records it must hold."""
+    from mi3d import _lib
+    ws = _lib.lib().mi3d_grid_scatter_binned_workspace
+    args = (13, 1.0, 2 * 3 ** 0.5 / 1024, 16, 16, 1.3819128274917603, 19)
+    full32, full16 = ws(10_878_592, *args, 0), ws(10_878_592, *args, 1)
+    half32 = ws(5_439_296, *args, 0)
+    assert 0 < full16 < full32 and half32 < full32
+    # levels 8..15 emit 8 records of 8 bytes per (evaluation, level) in the binary16 layout
+    assert full16 > 10_878_592 * 13 * 8 * 8 * 8
+    assert full32 < 300e9 and ws(0, *args, 0) == 0
