@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """SDS train-steps/sec of Make-It-3D's coarse stage on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2_dense|c2_pruned|c4_pruned|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2_dense|c2_pruned|c4_views|small]
 
 One step = one pass of the hot path over one novel view (BASELINE config 2): 128x128 rays, max_steps 1024,
 16-level hash grid + 3x64 MLP (fp16 autocast), march -> 13-point field -> composite, SD2-base-shaped U-Net noise
@@ -9,22 +9,34 @@ prediction (batch 2, CFG) + VAE encode, SDS gradient + regularisers, backward, c
 reference's orbit poses, random-init weights, analytic occupancy (dense = all ones: every ray emits ~664 samples,
 m ~ 10.9 M samples/step).  Inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own view (phi = 30 + 45 k
-degrees) and the NeRF gradients are averaged with one flat RCCL all-reduce per step; `value` counts view-steps of all
-ranks per second (weak scaling).
+`--gpus N` with N > 1 starts N ranks itself (re-exec under torch.distributed.run, one rank per GPU) unless it is
+already running inside such a launch (WORLD_SIZE set, as the driver does); a world size that differs from --gpus is
+an error.  Every rank renders its own view (phi = 30 + 45 k degrees), the NeRF gradients are averaged with one flat
+RCCL all-reduce per step; `value` counts view-steps of all ranks per second (weak scaling).
+
+The HEADLINE (`value`, `ms_per_step`) is the like-for-like configuration: what the reference's main.py gets with the
+drop-in packages and NO edits to nerf/sd.py / nerf/utils.py - the reference's two-backward SDS schedule
+(`latents.backward(retain_graph=True)` then `scaler.scale(loss).backward()`) - and fp32 gradient records in the
+hash-grid scatter (tiny-cuda-nn adds fp32 products).  `variants` reports the other three corners of
+{records: fp32 | half} x {sds_backward: reference | single}, each timed on its own steps.
 
 The JSON line also carries
-  roofline     : the dominant single kernel (the 13-point hash-grid gather, `k_grid_encode`) - algorithmic bytes per
-                 launch (1024 B per field evaluation = 16 levels x 8 corners x 2 floats) over its average
-                 launch duration measured with HIP events on the launch stream during the timed steps; the other hot
-                 kernels (gradient scatter, MLP forward/backward) are listed the same way under rooflines_other;
-  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) rendering a bounded ray sample of the
-                 same workload on this box's host cores, extrapolated to a full view (forward render only).
+  roofline     : the step's dominant kernel - algorithmic bytes per launch (1024 B per field evaluation
+                 gathered, 2048 B read-modify-written by the scatter) over its launch duration measured with HIP events
+                 on the launch stream during the timed steps; the other hot kernels under rooflines_other; `traffic` =
+                 HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r02.json);
+  cpu_baseline : the reference's own pure-PyTorch renderer (nerf/renderer.py:332-479 `run` + nerf/network_tcnn.py on a
+                 torch hash grid; staged sources, oracle/_ref/py) forward + backward on a bounded ray sample on this
+                 box's host cores (kind "reference"); the C oracle port when the staged sources are absent ("port");
+  reference_shaped_baseline : the SAME step with the reference's own NeRFNetwork / run_cuda Python running unchanged
+                 on the drop-in raymarching + tinycudann packages (13 encoder passes, torch MLP, atomic scatter) on
+                 this GPU - the zero-change integration route and the only same-GPU anchor the north-star's ">= 10x"
+                 can have (the reference's CUDA build cannot run here).
 """
 import argparse
 import json
-import math
 import os
+import subprocess
 import sys
 import time
 
@@ -33,36 +45,94 @@ for _p in (ROOT, os.path.join(ROOT, "make-it-3d_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 WORKLOADS = {
-    # name: (H, W, max_steps, bitfield, views_per_rank)
-    "c2_dense": dict(H=128, W=128, max_steps=1024, bitfield="dense"),
-    "c2_pruned": dict(H=128, W=128, max_steps=1024, bitfield=0.3),
-    "c4_pruned": dict(H=256, W=256, max_steps=2048, bitfield=0.5),
-    "small": dict(H=32, W=32, max_steps=128, bitfield="dense"),
+    # name: H, W, max_steps, analytic occupancy, views rendered per step and rank
+    "c2_dense": dict(H=128, W=128, max_steps=1024, bitfield="dense", views=1),
+    "c2_pruned": dict(H=128, W=128, max_steps=1024, bitfield=0.3, views=1),
+    # BASELINE config 4: forward render of a batch of 4 views, pruned occupancy, 7 field evaluations per
+    # sample (no smoothness pass) - the hash-gather stress; value = view-renders/s, no backward / optimizer
+    "c4_views": dict(H=256, W=256, max_steps=2048, bitfield=0.5, views=4, mode="render"),
+    "small": dict(H=32, W=32, max_steps=128, bitfield="dense", views=1),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, same guide
 ENCODE_BYTES_PER_EVAL = 1024   # 16 levels x 8 corners x 2 features x 4 B gathered per field evaluation
 SCATTER_BYTES_PER_EVAL = 2048  # the same bytes read-modify-written by the gradient scatter
+T_FIXED = 500  # SDS branch under the reference's rule (nerf/sd.py:153: t/1000 <= 0.4 takes the CLIP branch instead)
+HEADLINE = ("fp32", "reference")
+
+
+def ensure_built():
+    """libmi3d.so is git-ignored: build it if this checkout has none (hipcc cross-compiles; seconds when cached)."""
+    so = os.path.join(ROOT, "make-it-3d_amd", "csrc", "libmi3d.so")
+    if not os.path.exists(so):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mi3d_build", os.path.join(ROOT, "make-it-3d_amd", "build.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        m.build()
+    return so
 
 
 def pmc_traffic(kernel, workload, evals):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_r01.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of tools/encode_bench.py on this workload, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's evaluation count; None if not collected."""
-    path = os.path.join(ROOT, "profiles", "pmc_r01.json")
-    try:
-        rec = json.load(open(path))[kernel][workload]
-        return rec["hbm_bytes_per_eval"] * evals
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's
+    evaluation count; None if not collected."""
+    for name in ("pmc_r02.json", "pmc_r01.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
+            return rec["hbm_bytes_per_eval"] * evals
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(wl, budget_s=20.0):
-    """Oracle (CPU port) forward render of a ray sample of this workload; returns the cpu_baseline object."""
+def cpu_baseline_reference(wl, budget_s=20.0):
+    """The reference's own PyTorch renderer on the host cores: NeRFRenderer.run (renderer.py:332-479, max_steps
+    uniform samples per ray, no importance pass) + NeRFNetwork.forward / normal (13 field evaluations per sample with
+    the smoothness term) on a torch hash grid, forward + backward of a render loss, on a ray sample of the same view."""
+    import torch
+    from mi3d import rays as R
+    from oracle import ref_import
+    ref_import.install()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    opt = ref_import.default_opt(cuda_ray=False, lambda_smooth=1.0, max_steps=wl["max_steps"])
+    torch.manual_seed(0)
+    net = ref_import.reference_network(opt, "oracle")
+    net.train()
+    ro, rd, _ = R.view_rays(wl["H"], wl["W"])
+    N = ro.shape[1]
+    steps = wl["max_steps"]
+
+    def render(n):
+        idx = torch.randperm(N)[:n]
+        net.zero_grad()
+        out = net.render(ro[:, idx], rd[:, idx], staged=False, num_steps=steps, upsample_steps=0, perturb=True,
+                         bg_color=torch.rand(n, 3), ambient_ratio=1.0, shading="albedo")
+        loss = (out["image"] ** 2).mean() + out["loss_orient"] + out["loss_smooth"]
+        loss.backward()
+
+    # the torch hash grid pays a large fixed cost per pass (a dense 48.8 MB gradient per encoder call), so grow the
+    # sample until one render fills about half the budget - a tiny sample would charge that fixed cost to a few rays
+    n, dt, spent = 8, 0.0, 0.0
+    for _ in range(4):
+        t0 = time.perf_counter()
+        render(n)
+        dt = time.perf_counter() - t0
+        spent += dt
+        if dt >= 0.5 * budget_s or n >= N or spent >= 2 * budget_s:
+            break
+        n = int(min(N, max(n + 1, min(16 * n, n * 0.8 * budget_s / max(dt, 1e-3)))))
+    return {"value": (n / N) / dt, "unit": "view-steps/s (render + backward only, no diffusion)", "cores": cores,
+            "kind": "reference",
+            "sample": f"{n} of {N} rays x {steps} samples x 13 field evaluations of the same view through the "
+                      f"reference's NeRFRenderer.run + NeRFNetwork (torch hash grid), forward + backward, {dt:.1f} s, "
+                      f"extrapolated to the full view"}
+
+
+def cpu_baseline_port(wl, budget_s=20.0):
+    """Fallback: the C oracle port (march + field + composite, forward only) on a ray sample."""
     import numpy as np
     from mi3d import rays as R
     from oracle import oracle as O
@@ -71,22 +141,16 @@ def cpu_baseline(wl, budget_s=20.0):
     ro, rd, _ = R.view_rays(wl["H"], wl["W"])
     o, d = ro.view(-1, 3).numpy(), rd.view(-1, 3).numpy()
     N = o.shape[0]
-    cfg = O.GridConfig()
-    fp = O.FieldParams(cfg)
+    fp = O.FieldParams(O.GridConfig())
     bits = np.full(128 ** 3 // 8, 255, np.uint8)
-    if wl["bitfield"] != "dense":
-        co = np.stack(np.meshgrid(*[np.arange(128)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
-        grid = np.zeros((1, 128 ** 3), np.float32)
-        grid[0, O.morton3D(co)] = np.linalg.norm((co + 0.5) / 128 * 2 - 1, axis=1) < float(wl["bitfield"])
-        bits = O.packbits(grid, 0.5)
     aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
 
     def render(idx):
         nears, fars = O.near_far_from_aabb(o[idx], d[idx], aabb)
         xyzs, dirs, deltas, rays = O.march_rays_train(o[idx], d[idx], 1.0, bits, 1, 128, nears, fars, align=128,
                                                       max_steps=wl["max_steps"])
-        sig, col, nrm = O.field_forward(xyzs, dirs, fp)           # 7 field evaluations per sample
-        O.field_normal(xyzs + np.float32(0.01), fp)               # + 6 for the smoothness term = 13
+        sig, col, nrm = O.field_forward(xyzs, dirs, fp)
+        O.field_normal(xyzs + np.float32(0.01), fp)
         O.composite_rays_train(sig, col, deltas, rays)
         return xyzs.shape[0]
 
@@ -100,8 +164,27 @@ def cpu_baseline(wl, budget_s=20.0):
     m = render(rng.choice(N, n, replace=False))
     dt = time.perf_counter() - t0
     return {"value": (n / N) / dt, "unit": "render-steps/s (forward only)", "cores": cores, "kind": "port",
-            "sample": f"{n} of {N} rays ({m} samples, 13 field evaluations each) of the same view, "
-                      f"oracle march+field+composite, {dt:.1f} s, extrapolated to the full view"}
+            "sample": f"{n} of {N} rays ({m} samples, 13 field evaluations each), C oracle march+field+composite, "
+                      f"{dt:.1f} s, extrapolated to the full view"}
+
+
+def cpu_baseline(wl):
+    try:
+        from oracle import ref_import
+        if ref_import.available():
+            return cpu_baseline_reference(wl)
+    except Exception as e:  # fall through to the port, but say why
+        sys.stderr.write(f"[bench] reference CPU baseline unavailable: {e!r}\n")
+    return cpu_baseline_port(wl)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: become the launcher (one rank per GPU on this node)."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -110,22 +193,32 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_dense", choices=list(WORKLOADS))
-    ap.add_argument("--sds-backward", default="single", choices=["single", "reference"])
+    ap.add_argument("--variant-steps", type=int, default=4, help="timed steps of each non-headline variant (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-shaped", action="store_true")
     ap.add_argument("--init-scale", type=float, default=0.25, help="GradScaler initial loss scale")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"bench invalid: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    ensure_built()
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     wl = WORKLOADS[args.workload]
+    views = wl["views"]
 
-    from mi3d import dp, grid_ops, rays as R, sd_standin, sds_step
+    from mi3d import dp, field_ops, grid_ops, rays as R, sd_standin, sds_step
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
     # GradScaler: the reference constructs it at 65536 (nerf/utils.py:309).  On this workload the normal-smoothness
     # regulariser back-propagates through safe_normalize of finite differences that fp16 rounds to exactly zero
@@ -139,113 +232,199 @@ def main():
     bucket = dp.FlatGradBucket(model.parameters())
     guidance = sd_standin.StableDiffusionStandIn(dev)
     text_z = guidance.get_text_embeds()
-    ro, rd, ds = R.view_rays(wl["H"], wl["W"], view=rank, device=dev)
-    t_fixed = torch.tensor([400], dtype=torch.long, device=dev)  # t fixed for timing
+    view_rays = [R.view_rays(wl["H"], wl["W"], view=rank * views + v, device=dev) for v in range(views)]
+    t_fixed = torch.tensor([T_FIXED], dtype=torch.long, device=dev)
     torch.manual_seed(1234 + rank)
 
-    def step():
-        bucket.zero()
-        return sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
-                                       sds_backward=args.sds_backward, t=t_fixed, grad_sync=bucket.all_reduce_mean)
+    render_only = wl.get("mode") == "render"
+    if render_only:
+        opt.lambda_smooth = 0.0
+
+    def make_step(the_model, the_optimizer, the_scaler, schedule, sync):
+        def render_step():
+            for ro, rd, ds in view_rays:
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+                    the_model.render(ro, rd, depth_scale=ds, bg_color=torch.rand(3, device=dev), staged=False,
+                                     perturb=True, ambient_ratio=1.0, shading="albedo", force_all_rays=True,
+                                     **sds_step.render_kwargs(opt))
+        if render_only:
+            return render_step
+
+        def step():
+            # a batch of `views` views is `views` consecutive single-view passes (the renderer "assumes B == 1",
+            # renderer.py:482), each a full training step as the reference's loader (batch_size 1) would issue them
+            for ro, rd, ds in view_rays:
+                if sync is not None:
+                    bucket.zero()
+                sds_step.sds_train_step(the_model, guidance, text_z, the_optimizer, the_scaler, ro, rd, ds, wl["H"],
+                                        wl["W"], opt, sds_backward=schedule, t=t_fixed, grad_sync=sync)
+        return step
 
     # phase timers (HIP events on the launch stream) around the two PyTorch-side phases
-    _sds, _opt_step = guidance.sds_gradient, optimizer.step
+    _sds, _train, _opt_step = guidance.sds_gradient, guidance.train_step, optimizer.step
 
-    def sds_timed(*a, **k):
-        box = []
-        grid_ops._timed("sd_guidance", lambda: box.append(_sds(*a, **k)), 1)
-        return box[0]
+    def timed(kind, fn):
+        def wrapper(*a, **k):
+            box = []
+            grid_ops._timed(kind, lambda: box.append(fn(*a, **k)), 1)
+            return box[0]
+        return wrapper
+    guidance.sds_gradient = timed("sd_guidance", _sds)
+    optimizer.step = timed("optimizer", _opt_step)
 
-    def opt_timed(*a, **k):
-        box = []
-        grid_ops._timed("optimizer", lambda: box.append(_opt_step(*a, **k)), 1)
-        return box[0]
-    guidance.sds_gradient, optimizer.step = sds_timed, opt_timed
+    def run(records, schedule, steps, warmup):
+        field_ops.HALF_RECORDS = records == "half"
+        step = make_step(model, optimizer, scaler, schedule, bucket.all_reduce_mean)
+        for _ in range(warmup):
+            step()
+        grid_ops.PROFILE = {"scatter": [], "encode": []}
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        prof, grid_ops.PROFILE = grid_ops.PROFILE, None
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        applied = len(prof.get("optimizer", []))
+        if not render_only and applied != steps * views:
+            raise SystemExit(f"bench invalid: only {applied} of {steps * views} timed passes applied their optimizer "
+                             f"update (GradScaler overflow, scale now {scaler.get_scale()})")
+        return elapsed, prof
 
-    for _ in range(args.warmup):
-        step()
-    grid_ops.PROFILE = {"scatter": [], "encode": []}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof, grid_ops.PROFILE = grid_ops.PROFILE, None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, prof = run(*HEADLINE, args.steps, args.warmup)
+    variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
+    if args.variant_steps > 0 and not render_only:
+        for rec in ("fp32", "half"):
+            for sch in ("reference", "single"):
+                if (rec, sch) != HEADLINE:
+                    e, _ = run(rec, sch, args.variant_steps, 1)
+                    variants[f"records={rec},sds_backward={sch}"] = 1e3 * e / args.variant_steps
+    field_ops.HALF_RECORDS = False
 
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
-    applied = len(prof.get("optimizer", []))
-    if applied != args.steps:
-        raise SystemExit(f"bench invalid: only {applied} of {args.steps} timed steps applied their optimizer update "
-                         f"(GradScaler overflow, scale now {scaler.get_scale()})")
+    line = None
     if rank == 0:
-        P = 13
         ms = {k: [a.elapsed_time(b) for a, b in v] for k, v in prof.items() if not k.endswith("_evals")}
-        avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in ms.items()}
-        evals = float(m) * P if not prof.get("encode_evals") else sum(prof["encode_evals"]) / len(prof["encode_evals"])
+        evals = {k[:-6]: v for k, v in prof.items() if k.endswith("_evals")}
 
-        def hbm_roof(kernel, key, bytes_per_eval, note):
-            t = avg.get(key, 0.0)
-            a = evals * bytes_per_eval / (t * 1e-3) / 1e9 if t > 0 else 0.0
-            return {"kernel": kernel, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": a / HBM_PEAK_GBPS, "traffic": None, "launches": len(ms.get(key, [])), "avg_launch_ms": t,
-                    "algorithmic_bytes_per_launch": evals * bytes_per_eval, "note": note}
+        def roof(kernel, key, per_eval, bound, peak, unit, note, pmc_key=None):
+            t = sum(ms.get(key, [])) * 1e-3
+            work = sum(evals.get(key, [])) * per_eval
+            a = work / t / (1e9 if bound == "hbm" else 1e12) if t > 0 else 0.0
+            n_launch = max(1, len(ms.get(key, [])))
+            traffic = None
+            if pmc_key is not None:
+                traffic = pmc_traffic(pmc_key, args.workload, sum(evals.get(key, [])) / n_launch)
+            return {"kernel": kernel, "bound": bound, "achieved": a, "peak": peak, "unit": unit, "frac": a / peak,
+                    "traffic": traffic, "launches": len(ms.get(key, [])), "avg_launch_ms": 1e3 * t / n_launch,
+                    "ms_per_step": 1e3 * t / args.steps,
+                    "algorithmic_work_per_launch": work / n_launch, "note": note}
 
-        def mfma_roof(kernel, key, flop_per_eval):
-            t = avg.get(key, 0.0)
-            a = evals * flop_per_eval / (t * 1e-3) / 1e12 if t > 0 else 0.0
-            return {"kernel": kernel, "bound": "mfma", "achieved": a, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": a / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(ms.get(key, [])),
-                    "avg_launch_ms": t, "algorithmic_flop_per_launch": evals * flop_per_eval}
-
-        # the dominant single kernel of the step: the stencil hash-grid gather (one launch per step, timed with HIP
-        # events on the launch stream); SURVEY 8(d): 16 levels x 8 corners x 8 B = 1024 B per field evaluation
-        roof = hbm_roof("k_grid_encode_planes (13-point hash-grid gather, one level pair per XCD, csrc/hashgrid.hip)", "encode",
-                        ENCODE_BYTES_PER_EVAL,
-                        "each XCD gathers from one L2-resident level at a time (FETCH_SIZE 16 GB/launch vs 191 GB for the "
-                        "all-levels kernel); the limit is the texture-address rate for divergent 8-byte gathers (about "
-                        "one line per clock per CU), HBM traffic is essentially the 128 B/evaluation feature write")
-        roof["traffic"] = pmc_traffic("k_grid_encode_planes", args.workload, evals)
-        others = [
-            hbm_roof("grid gradient scatter = k_bin_emit + k_bin_reduce per slice (records through HBM, no global "
-                     "atomics)", "scatter", SCATTER_BYTES_PER_EVAL,
-                     "algorithmic bytes = 2048 B/evaluation read-modify-write of the table; the binned path instead "
-                     "moves 8 records x 12 B per (evaluation, level) out and back"),
-            mfma_roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0),
-            mfma_roof("k_mlp_backward<F16> (recompute + dgrad + wgrad, both orientations)", "mlp_bwd", 25600.0),
+        roofs = [
+            roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, cell "
+                 "reuse; csrc/hashgrid.hip)", "encode", ENCODE_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS, "GB/s",
+                 "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
+                 "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
+                 "k_grid_encode_planes"),
+            roof("grid gradient scatter = k_bin_emit (+ k_bin_emit16 with half records) + k_bin_reduce per slice "
+                 "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
+                 "GB/s", "algorithmic bytes = 2048 B per evaluation read-modify-write of the table; the binned path "
+                 "moves 8 records x 12 B per (evaluation, level) out and back instead; one call per NeRF backward: the "
+                 "SDS pass reaches stencil point 0 only (1/13 of the evaluations), the regulariser pass all 13",
+                 "scatter_binned"),
+            roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
+                 "HBM-streaming bound: 144 B read + 16 B written per evaluation", "k_mlp_forward"),
+            roof("k_mlp_backward<F16> (recompute + dgrad + wgrad, both orientations, next tile prefetched)", "mlp_bwd",
+                 25600.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
+                 "144 B read + 128 B written per evaluation; 67 MFMAs per 32 rows", "k_mlp_backward"),
         ]
+        roofs.sort(key=lambda r: -r["ms_per_step"])
         line = {
-            "metric": "SDS train-steps/sec (NeRF render+SD U-Net fwd+bwd) @128x128",
-            "value": world * args.steps / elapsed, "unit": "view-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 grid + f16 MLP (autocast), f16 U-Net",
+            "metric": ("forward view-renders/sec (march + 7-point field + composite), BASELINE config 4" if render_only
+                       else "SDS train-steps/sec (NeRF render+SD U-Net fwd+bwd) @128x128"),
+            "value": world * views * args.steps / elapsed, "unit": "view-renders/s" if render_only else "view-steps/s",
+            "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 hash grid (fp32 gather, fp32 12-byte gradient records) + f16 MFMA MLP (torch.autocast "
+                     "semantics), f16 U-Net; variants with 'records=half' round each fine-level (8-15) gradient "
+                     "contribution to binary16",
             "data": "synthetic (reference orbit rays, random-init weights, analytic occupancy)",
             "config": {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
-                                   f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step, occupancy "
-                                   f"{wl['bitfield']}, {m} samples/view x 13 field evaluations",
-                       "views_per_step": world, "sds_backward": args.sds_backward,
-                       "optimizer_steps_applied": applied, "grad_scaler_scale": scaler.get_scale(),
+                                   f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step (t={T_FIXED}: the SDS "
+                                   f"branch of nerf/sd.py:153), occupancy {wl['bitfield']}, {m} samples/view x 13 "
+                                   f"field evaluations, {views} view(s) per step",
+                       "views_per_step": world * views, "sds_backward": HEADLINE[1], "gradient_records": HEADLINE[0],
+                       "optimizer_steps_applied": args.steps * views, "grad_scaler_scale": scaler.get_scale(),
                        "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad all-reduce)"},
-            "roofline": roof,
-            "rooflines_other": others,
+            "variants_ms_per_step": variants,
+            "roofline": roofs[0],
+            "rooflines_other": roofs[1:],
             "kernels_ms_per_step": {k: sum(v) / args.steps for k, v in ms.items()},
         }
-        if not args.no_cpu_baseline and world == 1:
+
+    # ---- baselines (rank 0 of a single-GPU run only; never part of the timed region above)
+    if rank == 0 and world == 1:
+        if not args.no_reference_shaped and not render_only:
+            try:
+                line["reference_shaped_baseline"] = reference_shaped(model, guidance, text_z, opt, view_rays[0], wl,
+                                                                     t_fixed, dev, args.init_scale)
+            except Exception as e:
+                line["reference_shaped_baseline"] = {"value": None, "error": repr(e)}
+            if line["reference_shaped_baseline"].get("value"):
+                line["speedup_vs_reference_shaped"] = line["value"] / line["reference_shaped_baseline"]["value"]
+        if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(wl)
             except Exception as e:  # the baseline leg must never take the bench line down with it
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def reference_shaped(model, guidance, text_z, opt, rays, wl, t_fixed, dev, init_scale, steps=2):
+    """The reference's own NeRFNetwork + NeRFRenderer.run_cuda Python (staged, oracle/_ref/py) on the drop-in
+    raymarching / tinycudann packages: same weights, same step (two-backward schedule, fp16 autocast, Adan)."""
+    import torch
+    from mi3d import optim, sds_step
+    from oracle import ref_import
+    if not ref_import.available():
+        return {"value": None, "error": "reference sources not staged (oracle/build_ref.py)"}
+    ref_model = ref_import.reference_network(opt, "dropin").to(dev)
+    ref_model.load_state_dict(model.state_dict())
+    ref_model.train()
+    torch.cuda.empty_cache()
+    optimizer = optim.Adan(ref_model.get_params(5 * opt.lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+    scaler = torch.amp.GradScaler("cuda", enabled=opt.fp16, init_scale=float(init_scale))
+    ro, rd, ds = rays
+
+    def step():
+        sds_step.sds_train_step(ref_model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
+                                sds_backward="reference", t=t_fixed)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del ref_model, optimizer
+    torch.cuda.empty_cache()
+    return {"value": 1.0 / dt, "unit": "view-steps/s", "ms_per_step": 1e3 * dt, "steps": steps,
+            "what": "reference nerf/network_tcnn.py + nerf/renderer.py:481-583 unchanged on the drop-in raymarching + "
+                    "tinycudann packages (13 hash-grid passes, torch nn.Linear MLP under autocast, atomic scatter), same "
+                    "SD stand-in, two-backward schedule, Adan", "peak_mem_GiB": peak}
 
 
 if __name__ == "__main__":

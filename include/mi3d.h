@@ -122,7 +122,9 @@ int mi3d_hashgrid_backward(const float *x, uint32_t n, const float *dout, uint32
  * nerf/renderer.py:521-524), each as a separate encoder pass.  These two entry points take the whole stencil:
  * point p of sample i is clamp(base + offsets[p], -bound, bound) with base = x[i] for p < P0 and x2[i] for
  * P0 <= p < P (x2 may be NULL when P0 == P), mapped to [0,1] as (pt + bound) / (2 bound) (network_tcnn.py:106).
- * Row (i*P + p) of `out` / `dout` holds the n_levels*2 features of that point.
+ * Rows are POINT-MAJOR: row (p*n + i) of `out` / `dout` holds the n_levels*2 features of point p of sample i, so the
+ * rows of one stencil point are contiguous (a backward pass that only reaches the first P' points - sigma / albedo
+ * alone reach point 0, the normal points 0..6 - runs on that prefix of the rows and nothing else).
  * `count` (device int32, may be NULL) caps n at min(n, *count) without a host round trip.
  * `step` (scatter only): the marching step dt_min in world units (0 = unknown); it only selects which levels
  * use run-merging vs lane-quad atomics, never the result. */
@@ -130,9 +132,9 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
                             const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *params,
                             uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
                             uint32_t log2_hashmap_size, float *out, void *stream);
-/* mi3d_grid_encode_points with level-major output planes [n_levels][n*P][2] (feature pair of level l, row r at
- * out_planes[(l*n*P + r)*2]) - the layout the MLP kernels take with x_planes != 0.  Workgroups are tied to level pairs
- * by XCD so each XCD's L2 only ever holds the tables of the level it is gathering from. */
+/* mi3d_grid_encode_points with level-major output planes [n_levels][P*n][2] (feature pair of level l, row r = p*n + i
+ * at out_planes[(l*P*n + r)*2]) - the layout the MLP kernels take with x_plane_rows = P*n.  The (level, tile) work is
+ * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from. */
 int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
                                    uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
@@ -145,7 +147,8 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
 /* The same scatter without global atomics: every corner contribution (equal-cell runs of neighbouring samples
  * summed first on the coarse levels) is appended as a 12-byte record to the region of its 64-KB gradient bin, then
  * each bin is accumulated in LDS and added to the table (see hashgrid.hip).
- * `dout_planes` is level-major [n_levels][n*P][2] (what mi3d_mlp_backward writes with dx_planes != 0).
+ * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
+ * dx_plane_rows = P*n).
  * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
  * it; with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
  * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice.
@@ -165,32 +168,35 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 
 /* network_tcnn.py:13-32: y = W3 relu(W2 relu(W1 x + b1) + b2) + b3, torch nn.Linear layout (W_l is [out_l, in_l]
- * row-major fp32, the master weights).  x [n, dim_in] fp32 rows, or with x_planes != 0 level-major planes
- * [dim_in/2][n][2]; out [n, dim_out] fp32.
+ * row-major fp32, the master weights).  x [n, dim_in] fp32 rows (x_plane_rows == 0), or level-major planes
+ * [dim_in/2][x_plane_rows][2] of which the first n rows are processed (x_plane_rows >= n); out [n, dim_out] fp32.
  * half_mode != 0 reproduces torch.autocast(float16) around the stack (nerf/utils.py:979): inputs, weights, biases
  * and every layer output are rounded to binary16, products accumulate in fp32 (v_mfma_f32_32x32x16_f16);
  * half_mode == 0 is exact fp32 (v_mfma_f32_32x32x2_f32).  Supported shape: dim_in 32, dim_hidden 64, dim_out 4,
  * three layers (what network_tcnn.py:67 builds for the default 16-level grid); anything else returns
  * hipErrorInvalidValue - ask mi3d_mlp_supported() first. */
 int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, uint32_t num_layers);
-int mi3d_mlp_forward(const float *x, int x_planes, uint32_t n, const float *W1, const float *b1, const float *W2,
-                     const float *b2,
+int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const float *W1, const float *b1,
+                     const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream);
 /* Backward of the above for upstream gradient dout [n, dim_out]: writes dx and ACCUMULATES the weight and bias
  * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
- * dx_planes == 0: dx is [n, dim_in] rows; dx_planes != 0: dx is level-major planes [dim_in/2][n][2] (feature pair
- * (2l, 2l+1) of row r at dx[(l*n + r)*2]), the layout mi3d_grid_scatter_binned consumes, and `level_absmax`
- * (device float[dim_in/2], zeroed by the caller, may be NULL) receives max |dx| per level. */
-int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t n, const float *W1, const float *b1,
-                      const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes,
+ * dx_plane_rows == 0: dx is [n, dim_in] rows; otherwise dx is level-major planes [dim_in/2][dx_plane_rows][2]
+ * (feature pair (2l, 2l+1) of row r at dx[(l*dx_plane_rows + r)*2]), the layout mi3d_grid_scatter_binned consumes,
+ * and `level_absmax` (device float[dim_in/2], zeroed by the caller, may be NULL) receives max |dx| per level - +inf
+ * as soon as a level holds a non-finite value (the binned scatter then poisons that level with NaN, as the float
+ * atomics of the reference would). */
+int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1,
+                      const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                      uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx,
+                      uint32_t dx_plane_rows,
                       float *level_absmax, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream);
 
 /* ------------------------------------------------------------------ Part 5: the field head */
 
-/* From the MLP output h [n, P, 4] of the stencil points (P = 7: sample + its six +-epsilon neighbours in the order
+/* From the MLP output h [P, n, 4] (point-major rows p*n + i) of the stencil points (P = 7: sample + its six +-epsilon neighbours in the order
  * +x,-x,+y,-y,+z,-z; P = 13: plus the six neighbours of x2) to what the renderer consumes, in one elementwise pass:
  *   sigma [n]     = exp(h_0[0] + blob(x))                         network_tcnn.py:94-100,109, activation.py:5-18
  *   albedo [n,3]  = sigmoid(h_0[1..3])                            network_tcnn.py:110
@@ -200,12 +206,14 @@ int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t 
 int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon, float *sigma,
                             float *albedo, float *normal, float *normal2, void *stream);
-/* Backward: upstream gradients (any may be NULL = zero) -> dh [n, P, 4]; trunc_exp's clamped derivative
- * (activation.py:15-18), clamp and nan_to_num pass gradients exactly where torch's do. */
+/* Backward: upstream gradients (any may be NULL = zero) -> dh [P_active, n, 4], the rows of the first P_active
+ * points only: 1 (sigma / albedo alone carry a gradient: the SDS pass), 7 (+ normal) or 13 (+ normal2); the caller
+ * runs the MLP backward and the scatter over that prefix.  trunc_exp's clamped derivative (activation.py:15-18),
+ * clamp and nan_to_num pass gradients exactly where torch's do. */
 int mi3d_field_head_backward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
-                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon,
-                             const float *dsigma, const float *dalbedo, const float *dnormal, const float *dnormal2,
-                             float *dh, void *stream);
+                             uint32_t P, uint32_t P_active, float bound, float blob_density, float blob_radius,
+                             float epsilon, const float *dsigma, const float *dalbedo, const float *dnormal,
+                             const float *dnormal2, float *dh, void *stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mi3d.h"
+#include "mi3d_dev.h"
 
 namespace {
 
@@ -95,6 +96,18 @@ struct F16 {
         }
         return k;
     }
+    // accumulator tile -> K-block, no activation (the values are binary16-exact already: products with the identity)
+    __device__ static __forceinline__ KB cast(const f32x16 &acc) {
+        KB k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 pr = {acc[2 * j], acc[2 * j + 1]};
+            const half2v hv = __builtin_convertvector(pr, half2v);
+            k.v[j >> 2][2 * (j & 3)] = hv[0];
+            k.v[j >> 2][2 * (j & 3) + 1] = hv[1];
+        }
+        return k;
+    }
     // fp32 sum of the 16 values of a K-block (v_dot2_f32_f16 against ones)
     __device__ static __forceinline__ float sum(const KB &k) {
         float s = 0.f;
@@ -143,6 +156,12 @@ struct F32 {
         for (int q = 0; q < 16; ++q) k.v[q] = act.v[q] > 0.f ? d[q] : 0.f;
         return k;
     }
+    __device__ static __forceinline__ KB cast(const f32x16 &acc) {
+        KB k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) k.v[q] = acc[q];
+        return k;
+    }
     __device__ static __forceinline__ float sum(const KB &k) {
         float s = 0.f;
 #pragma unroll
@@ -163,8 +182,10 @@ enum : int {
     B_W3T = B_W3 + NTH,    // [tn]      N = hidden-2 feature, K = output index (X, < 4)  W3[K][N]
     B_W2T = B_W3T + NTH,   // [tn][tk]  N = hidden-1 feature, K = hidden-2 feature (D)   W2[K][N]
     B_W1T = B_W2T + NTH * NTH, // [tk]  N = input feature, K = hidden-1 feature (D)      W1[K][N]
+    B_ID = B_W1T + NTH,    //           N = index j, K = index k (X): (j == k) - as the B operand of a tile held
+                           //           "lane = sample" it hands back the tile "lane = index" (a transpose on the matrix core)
     B_FWD_COUNT = B_W3T,
-    B_ALL_COUNT = B_W1T + NTH,
+    B_ALL_COUNT = B_ID + 1,
 };
 
 struct Weights {
@@ -194,9 +215,11 @@ __device__ void build_blocks(char *lds, float *bias /* [HID + HID + 32] */, cons
         } else if (blk < B_W1T) {
             const int tn = (blk - B_W2T) / NTH, tk = (blk - B_W2T) % NTH;
             v = w.W2[(32 * tk + kd) * HID + 32 * tn + nl];
-        } else {
+        } else if (blk < B_ID) {
             const int tk = blk - B_W1T;
             v = w.W1[(32 * tk + kd) * DIN + nl];
+        } else {
+            v = nl == kx ? 1.f : 0.f;
         }
         // value q of lane sits in 16-byte unit q / per_unit
         constexpr int per_unit = 16 / (int)sizeof(T);
@@ -214,41 +237,64 @@ __device__ void build_blocks(char *lds, float *bias /* [HID + HID + 32] */, cons
 
 // ---------------------------------------------------------------- tile pieces
 // rows of the tile as a K-block (kind X): lane (p, h) holds features 16 h .. 16 h + 15 of row row0 + p.
-// x is either [n, DIN] rows or (planes) level-major [DIN/2][n][2]: feature pair (2l, 2l+1) of row r at x[(l n + r) 2].
-template <class P>
-__device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, bool valid, int h,
-                                                       bool planes, size_t n) {
-    typename P::KB k;
-    if (!planes) {
+// x is either [n, DIN] rows or (plane_rows != 0) level-major planes [DIN/2][plane_rows][2]: feature pair (2l, 2l+1) of
+// row r at x[(l plane_rows + r) 2]; plane_rows >= n lets a caller process a prefix of the rows of wider planes.
+// The 16 floats are fetched raw (so the backward can have the next tile's in flight while it computes) and turned into
+// the precision's K-block afterwards.
+// Rows past n are read from row n - 1 instead of being predicated off (no exec-mask branches around the loads, so all
+// of them are in flight together); their products are harmless: every weight-gradient term carries a factor dout,
+// which IS zeroed for those rows, and their outputs are never stored.
+__device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_t row, size_t n, int h,
+                                              size_t plane_rows, float (&raw)[16]) {
+    row = row < n ? row : n - 1;
+    if (plane_rows == 0) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (valid) t = src[c];
+            const f32x4 t = src[c];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) P::set(k, 4 * c + i, t[i]);
+            for (int i = 0; i < 4; ++i) raw[4 * c + i] = t[i];
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {  // 32 consecutive rows of one plane per load: 256 contiguous bytes per lane-half
-            f32x2 t = {0.f, 0.f};
-            if (valid) t = *reinterpret_cast<const f32x2 *>(x + ((size_t)(8 * h + j) * n + row) * 2);
-            P::set(k, 2 * j, t[0]);
-            P::set(k, 2 * j + 1, t[1]);
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(x + ((size_t)(8 * h + j) * plane_rows + row) * 2);
+            raw[2 * j] = t[0];
+            raw[2 * j + 1] = t[1];
         }
     }
+}
+template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float (&raw)[16]) {
+    typename P::KB k;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) P::set(k, q, raw[q]);
     return k;
+}
+template <class P>
+__device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, size_t n, int h,
+                                                       size_t plane_rows) {
+    float raw[16];
+    load_rows_raw(x, row, n, h, plane_rows, raw);
+    return rows_kb<P>(raw);
 }
 
 // [rows,4] output-side gradient as a K-block (kind X over the 4 outputs): only lane-half 0, q < 4 are non-zero
-template <class P>
-__device__ __forceinline__ typename P::KB load_dout_kb(const float *__restrict__ dout, size_t row, bool valid, int h) {
+// (the zeroing of rows past n and of lane-half 1 happens at the use, one iteration after the load was issued)
+__device__ __forceinline__ f32x4 load_dout_raw(const float *__restrict__ dout, size_t row, size_t n) {
+    return *reinterpret_cast<const f32x4 *>(dout + (row < n ? row : n - 1) * DOUT);
+}
+template <class P> __device__ __forceinline__ typename P::KB dout_kb(const f32x4 &t, bool keep) {
     typename P::KB k;
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    if (valid && h == 0) t = *reinterpret_cast<const f32x4 *>(dout + row * DOUT);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) P::set(k, q, q < 4 ? t[q] : 0.f);
+    for (int q = 0; q < 16; ++q) P::set(k, q, (q < 4 && keep) ? t[q] : 0.f);
     return k;
+}
+
+// max(m, |a|, |b|), or +inf as soon as a or b is not finite: the per-level maxima double as the overflow signal of
+// the binned scatter (fmaxf alone would drop a NaN)
+__device__ __forceinline__ float absmax_or_inf(float m, float a, float b) {
+    const bool finite = fabsf(a) <= 3.4028234663852886e38f && fabsf(b) <= 3.4028234663852886e38f;
+    return finite ? fmaxf(m, fmaxf(fabsf(a), fabsf(b))) : __builtin_inff();
 }
 
 __device__ __forceinline__ f32x16 splat(float v) {
@@ -266,7 +312,7 @@ __device__ __forceinline__ f32x16 bias_rows(const float *bias, int h) {
 }
 // ---------------------------------------------------------------- forward
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, int x_planes, uint32_t n,
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t x_planes, uint32_t n,
                                                                      Weights w, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_FWD_COUNT * block_bytes<P>());
@@ -286,7 +332,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row = (size_t)tile * 32 + p;
         const bool valid = row < n;
-        const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
+        const typename P::KB X = load_rows_kb<P>(x, row, n, h, x_planes);
         typename P::KB H1[NTH], H2[NTH];
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
@@ -317,9 +363,10 @@ struct Grads {
 };
 
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x, int x_planes,
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
                                                                       const float *__restrict__ dout, uint32_t n,
-                                                                      Weights w, float *__restrict__ dx, int dx_planes,
+                                                                      Weights w, float *__restrict__ dx,
+                                                                      uint32_t dx_planes,
                                                                       float *__restrict__ level_absmax, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
@@ -350,11 +397,26 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
 #pragma unroll
     for (int j = 0; j < 8; ++j) lvmax[j] = 0.f;
 
+    // One wave per SIMD (the weight-gradient tiles alone are 128 registers), so nothing hides a load but the wave's own
+    // work: the rows of the NEXT tile are requested before the current tile's products start and are consumed one
+    // iteration later (round 1 waited ~6.7 us per tile for its own rows, 5 % of the matrix peak).
+    float raw[16];
+    f32x4 dor = {0.f, 0.f, 0.f, 0.f};
+    if (wave < n_tiles) {
+        const size_t r0 = (size_t)wave * 32 + p;
+        load_rows_raw(x, r0, n, h, x_planes, raw);
+        dor = load_dout_raw(dout, r0, n);
+    }
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row0 = (size_t)tile * 32, row = row0 + p;
         const bool valid = row < n;
-        const typename P::KB X = load_rows_kb<P>(x, row, valid, h, x_planes != 0, n);
-        const typename P::KB dO = load_dout_kb<P>(dout, row, valid, h);
+        const typename P::KB X = rows_kb<P>(raw);
+        const typename P::KB dO = dout_kb<P>(dor, valid && h == 0);
+        if (tile + n_waves < n_tiles) {
+            const size_t rn = (size_t)(tile + n_waves) * 32 + p;
+            load_rows_raw(x, rn, n, h, x_planes, raw);
+            dor = load_dout_raw(dout, rn, n);
+        }
 
         // ---- orientation 1 (lane = sample): recompute the activations (they double as their own ReLU masks)
         typename P::KB H1[NTH], H2[NTH];
@@ -398,16 +460,16 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
                     __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
                 }
             } else if (valid) {
-                // level-major planes [DIN/2][n][2] (what the binned scatter reads): features (2l, 2l+1) of this row
-                // are one 8-byte store; lane-half h owns levels 4c + 2h and 4c + 2h + 1, 32 consecutive rows per store
+                // level-major planes [DIN/2][dx_planes][2] (what the binned scatter reads): features (2l, 2l+1) of this
+                // row are one 8-byte store; lane-half h owns levels 4c + 2h and 4c + 2h + 1, 32 consecutive rows per store
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     f32x2 a = {acc[4 * c], acc[4 * c + 1]}, b = {acc[4 * c + 2], acc[4 * c + 3]};
-                    lvmax[2 * c] = fmaxf(lvmax[2 * c], fmaxf(fabsf(a[0]), fabsf(a[1])));
-                    lvmax[2 * c + 1] = fmaxf(lvmax[2 * c + 1], fmaxf(fabsf(b[0]), fabsf(b[1])));
+                    lvmax[2 * c] = absmax_or_inf(lvmax[2 * c], a[0], a[1]);
+                    lvmax[2 * c + 1] = absmax_or_inf(lvmax[2 * c + 1], b[0], b[1]);
                     const size_t lvl = 4 * c + 2 * h;
-                    __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * n + row) * 2));
-                    __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * n + row) * 2));
+                    __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * dx_planes + row) * 2));
+                    __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * dx_planes + row) * 2));
                 }
             }
         }
@@ -421,14 +483,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
             P::mma(acc, X, blk(B_W1 + t));
             H1p[t] = P::relu(acc);
         }
-        // dO with lane = output index, values = samples (A operand of dW3); its sum over samples is db3
+        // dO with lane = output index, values = samples (A operand of dW3): dO (lane = sample) times the identity block
+        // hands it back transposed; its sum over samples is db3
         typename P::KB dOp;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const size_t r = row0 + rowmap(q, h);
-            const float v = (p < DOUT && r < n) ? dout[r * DOUT + p] : 0.f;
-            P::set(dOp, q, v);
-            gb3 += v;
+        {
+            f32x16 acc = splat(0.f);
+            P::mma_lo(acc, dO, blk(B_ID));
+            dOp = P::cast(acc);
+            gb3 += P::sum(dOp);
         }
         // hidden-2 pre-activations (for the mask and for dW3), gradient wrt hidden-2
 #pragma unroll
@@ -448,12 +510,13 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
         for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
             for (int tj = 0; tj < NTH; ++tj) P::mma(gW2[ti][tj], dH2p[ti], H1p[tj]);
-        // gradient wrt hidden-1 in orientation 2, then dW1[i][j] += sum_s dH1[s][i] X[s][j]
+        // the input rows with lane = input feature (X times the identity block), then the gradient wrt hidden-1 in
+        // orientation 2 and dW1[i][j] += sum_s dH1[s][i] X[s][j]
         typename P::KB Xp;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const size_t r = row0 + rowmap(q, h);
-            P::set(Xp, q, r >= n ? 0.f : x_planes ? x[((size_t)(p >> 1) * n + r) * 2 + (p & 1)] : x[r * DIN + p]);
+        {
+            f32x16 acc = splat(0.f);
+            P::mma(acc, X, blk(B_ID));
+            Xp = P::cast(acc);
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
@@ -557,20 +620,20 @@ __global__ void k_head_forward(const float4 *__restrict__ h, HeadArgs a, uint32_
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     float bx[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
-    const float4 h0 = h[(size_t)s * a.P];
+    const float4 h0 = h[s];  // rows are point-major: (sample s, point p) at p*n + s, coalesced across the wave
     sigma[s] = expf(h0.x + head_gauss(a, bx, 0));
     albedo[(size_t)s * 3] = 1.0f / (1.0f + expf(-h0.y));
     albedo[(size_t)s * 3 + 1] = 1.0f / (1.0f + expf(-h0.z));
     albedo[(size_t)s * 3 + 2] = 1.0f / (1.0f + expf(-h0.w));
     float sg[6], nn[3], v[3], c;
 #pragma unroll
-    for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)s * a.P + 1 + p].x + head_gauss(a, bx, 1 + p));
+    for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)(1 + p) * n + s].x + head_gauss(a, bx, 1 + p));
     head_normal(sg, a.inv_2eps, nn, v, c);
     normal[(size_t)s * 3] = nn[0]; normal[(size_t)s * 3 + 1] = nn[1]; normal[(size_t)s * 3 + 2] = nn[2];
     if (a.P == 13) {
         float b2[3] = {a.x2[(size_t)s * 3], a.x2[(size_t)s * 3 + 1], a.x2[(size_t)s * 3 + 2]};
 #pragma unroll
-        for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)s * a.P + 7 + p].x + head_gauss(a, b2, 7 + p));
+        for (uint32_t p = 0; p < 6; ++p) sg[p] = expf(h[(size_t)(7 + p) * n + s].x + head_gauss(a, b2, 7 + p));
         head_normal(sg, a.inv_2eps, nn, v, c);
         normal2[(size_t)s * 3] = nn[0]; normal2[(size_t)s * 3 + 1] = nn[1]; normal2[(size_t)s * 3 + 2] = nn[2];
     }
@@ -603,37 +666,42 @@ __device__ __forceinline__ void head_normal_backward(const float u[6], float inv
     }
 }
 
-__global__ void k_head_backward(const float4 *__restrict__ h, HeadArgs a, uint32_t n, const float *__restrict__ dsigma,
-                                const float *__restrict__ dalbedo, const float *__restrict__ dnormal,
-                                const float *__restrict__ dnormal2, float4 *__restrict__ dh) {
+// dh holds the rows of the first P_active points only ([P_active * n, 4], point-major): 1 when only sigma / albedo
+// carry a gradient, 7 with the normal, 13 with the jittered normal - the MLP backward and the scatter behind it then
+// run over that prefix of the stencil and nothing else.
+__global__ void k_head_backward(const float4 *__restrict__ h, HeadArgs a, uint32_t n, uint32_t P_active,
+                                const float *__restrict__ dsigma, const float *__restrict__ dalbedo,
+                                const float *__restrict__ dnormal, const float *__restrict__ dnormal2,
+                                float4 *__restrict__ dh) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     float bx[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
-    const float4 h0 = h[(size_t)s * a.P];
+    const float4 h0 = h[s];
     float4 g0;
     g0.x = (dsigma ? dsigma[s] : 0.f) * expf(fminf(h0.x + head_gauss(a, bx, 0), 15.0f));
     const float a0 = 1.0f / (1.0f + expf(-h0.y)), a1 = 1.0f / (1.0f + expf(-h0.z)), a2 = 1.0f / (1.0f + expf(-h0.w));
     g0.y = dalbedo ? dalbedo[(size_t)s * 3] * a0 * (1.0f - a0) : 0.f;
     g0.z = dalbedo ? dalbedo[(size_t)s * 3 + 1] * a1 * (1.0f - a1) : 0.f;
     g0.w = dalbedo ? dalbedo[(size_t)s * 3 + 2] * a2 * (1.0f - a2) : 0.f;
-    dh[(size_t)s * a.P] = g0;
+    dh[s] = g0;
+    if (P_active < 7) return;
     float u[6], du[6], dn[3];
 #pragma unroll
-    for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)s * a.P + 1 + p].x + head_gauss(a, bx, 1 + p);
+    for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)(1 + p) * n + s].x + head_gauss(a, bx, 1 + p);
 #pragma unroll
     for (int d = 0; d < 3; ++d) dn[d] = dnormal ? dnormal[(size_t)s * 3 + d] : 0.f;
     head_normal_backward(u, a.inv_2eps, dn, du);
 #pragma unroll
-    for (uint32_t p = 0; p < 6; ++p) dh[(size_t)s * a.P + 1 + p] = make_float4(du[p], 0.f, 0.f, 0.f);
-    if (a.P == 13) {
+    for (uint32_t p = 0; p < 6; ++p) dh[(size_t)(1 + p) * n + s] = make_float4(du[p], 0.f, 0.f, 0.f);
+    if (a.P == 13 && P_active == 13) {
         float b2[3] = {a.x2[(size_t)s * 3], a.x2[(size_t)s * 3 + 1], a.x2[(size_t)s * 3 + 2]};
 #pragma unroll
-        for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)s * a.P + 7 + p].x + head_gauss(a, b2, 7 + p);
+        for (uint32_t p = 0; p < 6; ++p) u[p] = h[(size_t)(7 + p) * n + s].x + head_gauss(a, b2, 7 + p);
 #pragma unroll
         for (int d = 0; d < 3; ++d) dn[d] = dnormal2 ? dnormal2[(size_t)s * 3 + d] : 0.f;
         head_normal_backward(u, a.inv_2eps, dn, du);
 #pragma unroll
-        for (uint32_t p = 0; p < 6; ++p) dh[(size_t)s * a.P + 7 + p] = make_float4(du[p], 0.f, 0.f, 0.f);
+        for (uint32_t p = 0; p < 6; ++p) dh[(size_t)(7 + p) * n + s] = make_float4(du[p], 0.f, 0.f, 0.f);
     }
 }
 
@@ -653,7 +721,7 @@ template <class P> constexpr size_t lds_bytes(int n_blocks) {
 
 int grid_for(uint32_t n) {
     const uint32_t tiles = (n + 31) / 32, wgs = (tiles + kWavesPerWG - 1) / kWavesPerWG;
-    const uint32_t cap = 256 * 2;  // persistent: two workgroups per CU
+    const uint32_t cap = 256 * (uint32_t)MI3D_TUNE(MI3D_T_MLP_WGS_PER_CU, 2);  // persistent: two workgroups per CU
     return (int)(wgs < cap ? (wgs ? wgs : 1) : cap);
 }
 
@@ -669,36 +737,38 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
     return dims_ok(dim_in, dim_hidden, dim_out, num_layers) ? 1 : 0;
 }
 
-int mi3d_mlp_forward(const float *x, int x_planes, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream) {
-    if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
+    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n)) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const Weights w{W1, b1, W2, b2, W3, b3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_forward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_planes, n, w, out);
+                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, n, w, out);
     else
         hipLaunchKernelGGL(k_mlp_forward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_planes, n, w, out);
+                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, n, w, out);
     return (int)hipGetLastError();
 }
 
-int mi3d_mlp_backward(const float *x, int x_planes, const float *dout, uint32_t n, const float *W1, const float *b1,
+int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, int dx_planes,
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, uint32_t dx_plane_rows,
                       float *level_absmax, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream) {
-    if (!dims_ok(dim_in, dim_hidden, dim_out, 3)) return (int)hipErrorInvalidValue;
+    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
+        (dx_plane_rows != 0 && dx_plane_rows < n))
+        return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, level_absmax, g);
+                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_plane_rows, dout, n, w, dx, dx_plane_rows, level_absmax, g);
     else
         hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_planes, dout, n, w, dx, dx_planes, level_absmax, g);
+                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_plane_rows, dout, n, w, dx, dx_plane_rows, level_absmax, g);
     return (int)hipGetLastError();
 }
 
@@ -714,17 +784,17 @@ int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uin
 }
 
 int mi3d_field_head_backward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
-                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon,
-                             const float *dsigma, const float *dalbedo, const float *dnormal, const float *dnormal2,
-                             float *dh, void *stream) {
+                             uint32_t P, uint32_t P_active, float bound, float blob_density, float blob_radius,
+                             float epsilon, const float *dsigma, const float *dalbedo, const float *dnormal,
+                             const float *dnormal2, float *dh, void *stream) {
     if ((P != 7 && P != 13) || (P == 13 && x2 == nullptr)) return (int)hipErrorInvalidValue;
+    if ((P_active != 1 && P_active != 7 && P_active != 13) || P_active > P) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const HeadArgs a = make_head_args(x, x2, offsets_host, P, bound, blob_density, blob_radius, epsilon);
     hipLaunchKernelGGL(k_head_backward, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(h), a, n, dsigma, dalbedo, dnormal, dnormal2,
+                       reinterpret_cast<const float4 *>(h), a, n, P_active, dsigma, dalbedo, dnormal, dnormal2,
                        reinterpret_cast<float4 *>(dh));
     return (int)hipGetLastError();
 }
-
 
 }  // extern "C"

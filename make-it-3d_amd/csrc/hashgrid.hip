@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "../../include/mi3d.h"
+#include "mi3d_dev.h"
 #include "mi3d_grid.h"
 
 using namespace mi3d;
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
     __shared__ float tile[kTile * (kMaxFeat + 1)];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t n_rows = n;  // the row stride between points is the caller's n, whatever *count says
     if (count != nullptr) { const uint32_t c = (uint32_t)max(*count, 0); n = c < n ? c : n; }
     const uint32_t F = T.n_levels * 2, stride = F + 1;
     const uint32_t s0 = blockIdx.x * kTile, s = s0 + lane;
@@ -101,64 +103,188 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
             tile[lane * stride + 2 * l + 1] = r1;
         }
         __syncthreads();
-        // row of (sample i, point p) is i*P + p: one full 2L-float line per row
+        // row of (sample i, point p) is p*n + i (point-major): one full 2L-float line per row, 64 rows contiguous
         for (uint32_t e = threadIdx.x; e < rows * F; e += blockDim.x) {
             const uint32_t i = e / F, f = e % F;
-            out[((size_t)(s0 + i) * ps.P + p) * F + f] = tile[i * stride + f];
+            out[((size_t)p * n_rows + s0 + i) * F + f] = tile[i * stride + f];
         }
         __syncthreads();
     }
 }
 
-// ---------------------------------------------------------------- forward, level-major planes, one level pair per XCD
+// ---------------------------------------------------------------- forward, level-major planes, levels tied to XCDs
 // rocprofv3 on the row kernel above (profiles/pmc_r01.json): 191 GB of FETCH_SIZE per launch against 145 GB of
 // algorithmic gather bytes - every XCD touches all 16 levels (48.8 MB) through a 4 MB L2, so the hashed levels miss and
-// each 8-byte gather pulls a line across the fabric.  Here workgroup b serves levels (b % 8) and (b % 8) + 8 ONLY - the
-// dispatcher places block b on XCD b % 8 - for ALL samples, one level at a time, so the tables an XCD gathers from are
-// one coarse level plus one 4 MB hashed level at any moment and stay L2-resident.  Output is level-major planes
-// [L][n*P][2] (what the MLP kernels read with x_planes != 0); a tile's 64 x P rows are contiguous in a plane and
-// leave through an LDS stage in full lines.
+// each 8-byte gather pulls a line across the fabric.  Here the (level, tile) work list is cut into 8 contiguous
+// segments of equal modelled cost and the workgroups of XCD x (block b runs on XCD b % 8) walk segment x, one level at
+// a time: the table an XCD gathers from at any moment is one level (<= 4 MB) and stays L2-resident.
+// Output is level-major planes [L][P*n][2], row = p*n + s (point-major): the 64 lanes of a wave store 512 contiguous
+// bytes per point, and the MLP kernels read them with x_plane_rows = P*n.
+//
+// The gather itself is bound by the L1's line-lookup rate (one distinct line per clock per CU; round 1 measured 18.1 G
+// lane-addresses in 40 ms), so the kernel spends lookups sparingly:
+//   PAIR   the x and x+1 corners of a (y, z) corner pair are neighbours in memory whenever their entry indices differ
+//          in bit 0 only - every even cx on hashed levels (x enters the hash with prime 1), every even entry index on
+//          dense ones: one 16-byte load of the aligned slot serves both, the x+1 corner is fetched separately only
+//          where the pair straddles a slot.
+//   REUSE  on levels whose cells are longer than the finite-difference epsilon the six neighbours of a sample mostly
+//          sit in the sample's own cell: the 8 corner values of the sample's cell (and of the last other cell
+//          touched) stay in registers and a stencil point that lands in either re-uses them.  Same values, same
+//          summation order: bit-identical features.
 constexpr uint32_t kXcds = 8;
+constexpr int kMaxSegs = 16;
 
+struct EncodeSeg { uint32_t level, tile0, tile1; };
+struct EncodePlan {
+    uint32_t n_seg[kXcds];
+    EncodeSeg seg[kXcds][kMaxSegs];
+    uint32_t reuse_levels;  // levels below this keep two cells of corner values in registers
+};
+
+struct CellVals {
+    uint32_t cx, cy, cz;
+    float2 v[8];
+};
+
+template <bool PAIR>
+__device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 *__restrict__ lvl, uint32_t cx,
+                                               uint32_t cy, uint32_t cz, float2 (&v)[8]) {
+    if (!PAIR) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = lvl[grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))];
+        return;
+    }
+    uint32_t e0[4], e1[4];
+    float4 t[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        e0[j] = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
+        e1[j] = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
+        // the aligned 16-byte slot holding entry e0 (level bases and sizes are multiples of 8 entries)
+        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u));
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)  // the x+1 corner only where it is not the other half of that slot
+        if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = lvl[e1[j]];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const bool odd = e0[j] & 1u;
+        v[2 * j] = odd ? make_float2(t[j].z, t[j].w) : make_float2(t[j].x, t[j].y);
+        if ((e0[j] ^ e1[j]) == 1u) v[2 * j + 1] = odd ? make_float2(t[j].x, t[j].y) : make_float2(t[j].z, t[j].w);
+    }
+}
+
+template <bool PAIR, bool REUSE>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
-                                                                       float2 *__restrict__ planes) {
-    __shared__ float2 stage_all[kWaves][kTile * kMaxPts];
+                                                                       EncodePlan plan, float2 *__restrict__ planes) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    float2 *stage = stage_all[wave];
     const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
     const size_t rows_total = (size_t)n * ps.P;
-    for (uint32_t l = xcd; l < T.n_levels; l += kXcds) {
+    for (uint32_t sg = 0; sg < plan.n_seg[xcd]; ++sg) {
+        const EncodeSeg seg = plan.seg[xcd][sg];
+        const uint32_t l = seg.level;
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
         float2 *plane = planes + (size_t)l * rows_total;
-        for (uint32_t tile = wg_in_xcd * kWaves + wave; tile < n_tiles; tile += wgs_per_xcd * kWaves) {
+        const bool reuse = REUSE && l < plan.reuse_levels;
+        for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
             const uint32_t s = tile * kTile + lane;
             const bool valid = s < n;
             float base[2][3];
             load_bases(ps, s, valid, base);
+            CellVals A, B;  // A: the cell of point 0, B: the last other cell gathered
+            A.cx = A.cy = A.cz = B.cx = B.cy = B.cz = 0xFFFFFFFFu;
             for (uint32_t p = 0; p < ps.P; ++p) {
                 float q[3];
                 point_of(ps, base, p, q);
-                float r0 = 0.f, r1 = 0.f;
-                if (valid) {
-                    Corners c;
-                    grid_corners(L, q[0], q[1], q[2], c);
-                    float2 v[8];
+                uint32_t cx, cy, cz;
+                float fx, fy, fz;
+                grid_cell(q[0], L.scale, cx, fx);
+                grid_cell(q[1], L.scale, cy, fy);
+                grid_cell(q[2], L.scale, cz, fz);
+                float2 v[8];
+                bool need = valid;
+                if (REUSE && reuse) {
+                    const bool hitA = cx == A.cx && cy == A.cy && cz == A.cz;
+                    const bool hitB = cx == B.cx && cy == B.cy && cz == B.cz;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = lvl[c.idx[k]];  // 8 independent 8-byte gathers in flight
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { r0 += c.w[k] * v[k].x; r1 += c.w[k] * v[k].y; }
+                    for (int k = 0; k < 8; ++k) v[k] = hitA ? A.v[k] : B.v[k];
+                    need = valid && !(hitA || hitB);
                 }
-                stage[lane * ps.P + p] = make_float2(r0, r1);
+                if (need) {
+                    gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
+                    if (REUSE && reuse) {
+                        if (p == 0) {
+                            A.cx = cx; A.cy = cy; A.cz = cz;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) A.v[k] = v[k];
+                        } else {
+                            B.cx = cx; B.cy = cy; B.cz = cz;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) B.v[k] = v[k];
+                        }
+                    }
+                }
+                if (valid) {
+                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                    // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
+                    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+                    const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+                    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
+                    plane[(size_t)p * n + s] = make_float2(r0, r1);
+                }
             }
-            const uint32_t live = (n - tile * kTile < (uint32_t)kTile ? n - tile * kTile : (uint32_t)kTile) * ps.P;
-            float2 *dst = plane + (size_t)tile * kTile * ps.P;
-            for (uint32_t e = lane; e < live; e += kWave) dst[e] = stage[e];
         }
     }
+}
+
+// The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.  A level's cost per tile is the
+// share of its stencil points that still gather once cell reuse is on: a +-eps neighbour leaves its centre's cell with
+// probability ~ eps * scale (capped at 1); the centre points always gather.
+inline EncodePlan make_encode_plan(const GridTable &T, const PointSet &ps, uint32_t n_tiles, bool reuse, int only_level) {
+    EncodePlan plan{};
+    double span = 0.0;  // largest stencil offset in [0,1] units
+    for (uint32_t i = 0; i < ps.P * 3; ++i) span = fmax(span, fabs((double)ps.offs[i]));
+    span = ps.mode == 0 ? 0.0 : span / (2.0 * (double)ps.bound);
+    const uint32_t groups = ps.P0 < ps.P ? 2u : 1u;
+    double cost[MI3D_MAX_LEVELS], total = 0.0;
+    uint32_t reuse_levels = 0;
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        double hit = reuse && ps.P > 1 && span > 0.0 ? 1.0 - span * (double)T.level[l].scale : 0.0;
+        hit = hit < 0.0 ? 0.0 : hit;
+        if (hit > 0.15) reuse_levels = l + 1; else hit = 0.0;
+        cost[l] = 1.0 - hit * (double)(ps.P - groups) / (double)ps.P;
+        if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
+        total += cost[l];
+    }
+    plan.reuse_levels = reuse_levels;
+    const double share = total / kXcds;
+    uint32_t x = 0;
+    double filled = 0.0;  // cost already given to XCD x
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        if (cost[l] <= 0.0) continue;
+        uint32_t t0 = 0;
+        while (t0 < n_tiles) {
+            // tiles of this level that still fit XCD x's share (the last XCD takes whatever is left)
+            const double room = share - filled;
+            uint32_t take = (x + 1 == kXcds) ? n_tiles - t0 : (uint32_t)ceil(room / cost[l] * (double)n_tiles - 1e-9);
+            if (take > n_tiles - t0) take = n_tiles - t0;
+            if (take > 0 && plan.n_seg[x] < (uint32_t)kMaxSegs) {
+                plan.seg[x][plan.n_seg[x]++] = EncodeSeg{l, t0, t0 + take};
+                filled += cost[l] * (double)take / (double)n_tiles;
+                t0 += take;
+            }
+            if (t0 < n_tiles || filled >= share - 1e-12) {
+                if (x + 1 < kXcds) { ++x; filled = 0.0; }
+                else if (take == 0) break;  // cannot happen: the last XCD takes everything
+            }
+        }
+    }
+    return plan;
 }
 
 // ---------------------------------------------------------------- backward
@@ -205,6 +331,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
     grad_table += (size_t)(blockIdx.x % n_rep) * rep_stride;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t n_rows = n;
     if (count != nullptr) { const uint32_t c = (uint32_t)max(*count, 0); n = c < n ? c : n; }
     const uint32_t F = T.n_levels * 2;
     const uint32_t s0 = blockIdx.x * kTile;
@@ -220,7 +347,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
         for (uint32_t p = 0; p < ps.P; ++p) {
             float q[3];
             point_of(ps, base, p, q);
-            const size_t row = (size_t)s * ps.P + p;
+            const size_t row = (size_t)p * n_rows + s;  // point-major rows
             const float *drow = dout + row * F + f;
             for (uint32_t l = wave; l < T.n_levels; l += kWaves) {
                 if (!((level_mask >> l) & 1u)) continue;
@@ -267,7 +394,7 @@ constexpr int kRunStride = 17;  // floats per lane in the slab (16 values, padde
 
 __global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uint32_t n, const float *__restrict__ dout,
                                                                  GridTable T, uint32_t level_mask, uint32_t plane_rows,
-                                                                 uint32_t n_rep, size_t rep_stride, int debug,
+                                                                 uint32_t n_rep, size_t rep_stride,
                                                                  float *__restrict__ grad_table) {
     __shared__ float slab_all[kWaves][kWave * kRunStride];
     __shared__ uint32_t cell_all[kWaves][kWave * 3];   // cell of every lane
@@ -290,7 +417,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uin
         const GridLevel L = T.level[l];
         float *lvl = grad_table + (size_t)L.offset * 2;
         for (uint32_t p = 0; p < ps.P; ++p) {
-            const size_t row = (size_t)s * ps.P + p;
+            const size_t row = (size_t)p * n + s;  // point-major rows
             float d0 = 0.f, d1 = 0.f;
             if (valid) {
                 const float2 dd = plane_rows ? reinterpret_cast<const float2 *>(dout)[(size_t)l * plane_rows + row]
@@ -338,8 +465,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uin
                     const uint32_t k = i >> 1, f = i & 1u;
                     const uint32_t e = grid_entry(L, cells[first * 3] + (k & 1u), cells[first * 3 + 1] + ((k >> 1) & 1u),
                                                   cells[first * 3 + 2] + (k >> 2));
-                    if (debug & 4) { if (sum == 12345.678f) lvl[e] = sum; }
-                    else unsafeAtomicAdd(lvl + (size_t)e * 2 + f, sum);
+                    unsafeAtomicAdd(lvl + (size_t)e * 2 + f, sum);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -358,20 +484,16 @@ PointSet make_points(const float *x, const float *x2, const float *offsets_host,
 int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const float *dout, const GridTable &T,
                    uint32_t merge_levels, float *grad_params, hipStream_t st, uint32_t level_mask = 0xFFFFFFFFu,
                    uint32_t plane_rows = 0, uint32_t n_rep = 1, size_t rep_stride = 0) {
-    static const int force = getenv("MI3D_SCATTER") ? atoi(getenv("MI3D_SCATTER")) : -1;  // profiling A/B only
-    if (force >= 0) merge_levels = (uint32_t)force;
+    merge_levels = (uint32_t)MI3D_TUNE(MI3D_T_SCATTER_MERGE, merge_levels);
     if (merge_levels > T.n_levels) merge_levels = T.n_levels;
-    const char *lm = getenv("MI3D_SCATTER_LMASK");  // profiling only: restrict the scatter to a subset of levels
-    if (lm) level_mask &= (uint32_t)strtoul(lm, nullptr, 0);
+    level_mask &= (uint32_t)MI3D_TUNE(MI3D_T_SCATTER_LEVEL_MASK, 0x7FFFFFFF);
     level_mask &= (uint32_t)((1ull << T.n_levels) - 1);
     if (level_mask == 0) return 0;
     // levels where neighbouring samples share cells go through the runs kernel (it has no device-side count)
-    static const int no_runs = getenv("MI3D_SCATTER_NO_RUNS") ? atoi(getenv("MI3D_SCATTER_NO_RUNS")) : 0;
-    const uint32_t runs_mask = (count == nullptr && !no_runs) ? (level_mask & ((1u << merge_levels) - 1u)) : 0u;
+    const uint32_t runs_mask = (count == nullptr) ? (level_mask & ((1u << merge_levels) - 1u)) : 0u;
     if (runs_mask)
         hipLaunchKernelGGL(k_scatter_runs, dim3((n + kWave * kWaves - 1) / (kWave * kWaves)), dim3(kWave * kWaves), 0, st,
-                           ps, n, dout, T, runs_mask, plane_rows, n_rep, rep_stride,
-                           getenv("MI3D_BIN_DEBUG") ? atoi(getenv("MI3D_BIN_DEBUG")) : 0, grad_params);
+                           ps, n, dout, T, runs_mask, plane_rows, n_rep, rep_stride, grad_params);
     if (level_mask & ~runs_mask)
         hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
                            merge_levels, level_mask & ~runs_mask, plane_rows, n_rep, rep_stride, grad_params);
@@ -435,7 +557,6 @@ struct BinPlan {
     uint32_t half_mask;                     // levels stored as 8-byte {entry, half2} records through the staged emit
     uint32_t total_counts, total_max;
     uint32_t n_levels, n_bins;
-    uint32_t debug;  // profiling only (MI3D_BIN_DEBUG): 1 = reduce skips the LDS adds, 2 = emit skips the record stores
 };
 
 __host__ __device__ inline uint32_t level_bins(const GridLevel &L) { return (L.size + kBinEntries - 1) / kBinEntries; }
@@ -454,9 +575,8 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
 // not an error - the overflow goes to the table by atomics.
 inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels,
                         bool half_records) {
-    static const uint32_t fine_waves = getenv("MI3D_BIN_WAVES") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES")) : kEmitWavesMax;
-    static const uint32_t coarse_waves =
-        getenv("MI3D_BIN_WAVES_COARSE") ? (uint32_t)atoi(getenv("MI3D_BIN_WAVES_COARSE")) : 16384u;
+    const uint32_t fine_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_FINE_WAVES, kEmitWavesMax);
+    const uint32_t coarse_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_COARSE_WAVES, 16384);
     BinPlan p{};
     p.n_levels = T.n_levels;
     const uint64_t tiles = (n_slice + kWave - 1) / kWave;
@@ -500,8 +620,10 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
                                             float *__restrict__ grad_table, float &lmax) {
     const uint32_t b = e >> kBinShift;
     const uint32_t slot = atomicAdd(&fill[plan.level_bin0[l] + b], 1u);  // wave-private LDS counter
-    lmax = fmaxf(lmax, fmaxf(fabsf(g0), fabsf(g1)));
-    if (plan.debug & 2u) return;
+    // a non-finite contribution makes the level's maximum infinite: k_bin_reduce then poisons the level with NaN (the
+    // float atomics of the reference would have put the inf / NaN into the table)
+    const bool finite = fabsf(g0) <= 3.4028234663852886e38f && fabsf(g1) <= 3.4028234663852886e38f;
+    lmax = finite ? fmaxf(lmax, fmaxf(fabsf(g0), fabsf(g1))) : __builtin_inff();
     if (slot < plan.level_cap[l]) {
         BinRecord r{e, g0, g1};
         reinterpret_cast<BinRecord *>(reinterpret_cast<char *>(arena) + plan.level_base[l])[((size_t)gw * level_bins(L) + b) * plan.level_cap[l] + slot] = r;
@@ -514,6 +636,7 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
 
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
+                                                             uint32_t n_rows,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
                                                              uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
                                                              uint32_t waves_b, BinRecord *__restrict__ arena,
@@ -554,13 +677,14 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
             float lmax = 0.f;
             // the gradient pairs are fetched three points ahead of their use (the loop is latency-bound otherwise)
             const float2 zero2 = make_float2(0.f, 0.f);
-            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + (size_t)s * ps.P;
-            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[1] : zero2,
-                   d2 = (valid && 2 < ps.P) ? prow[2] : zero2;
+            // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
+            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + s;
+            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[(size_t)n_rows] : zero2,
+                   d2 = (valid && 2 < ps.P) ? prow[(size_t)2 * n_rows] : zero2;
             for (uint32_t p = 0; p < ps.P; ++p) {
                 const float2 d = d0;
                 d0 = d1; d1 = d2;
-                d2 = (valid && p + 3 < ps.P) ? prow[p + 3] : zero2;
+                d2 = (valid && p + 3 < ps.P) ? prow[(size_t)(p + 3) * n_rows] : zero2;
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
@@ -657,6 +781,7 @@ __device__ __forceinline__ float level_scale_exp(const float *level_absmax, uint
 
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                                const float *__restrict__ dplanes, uint32_t plane_rows,
+                                                               uint32_t n_rows,
                                                                GridTable T, BinPlan plan, uint32_t level_mask,
                                                                uint32_t n_waves, const float *__restrict__ level_absmax,
                                                                char *__restrict__ arena, uint32_t *__restrict__ counts,
@@ -679,7 +804,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint3
         uint32_t *cnt_out = counts + plan.level_cnt0[l] + (size_t)gw * bins;
         int kexp;
         const float amax = level_scale_exp(level_absmax, l, kexp);
-        if (!(amax > 0.f) || !(amax < 3.0e38f)) {  // nothing (or only non-finite values) on this level
+        if (!(amax > 0.f) || !(amax < 3.0e38f)) {  // nothing on this level, or non-finite values (k_bin_reduce poisons it)
             if ((uint32_t)lane < bins) cnt_out[lane] = 0;
             continue;
         }
@@ -768,13 +893,14 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint3
             float base[2][3];
             load_bases(ps, s, valid, base);
             const float2 zero2 = make_float2(0.f, 0.f);
-            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + (size_t)s * ps.P;
-            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[1] : zero2,
-                   d2 = (valid && 2 < ps.P) ? prow[2] : zero2;
+            // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
+            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + s;
+            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[(size_t)n_rows] : zero2,
+                   d2 = (valid && 2 < ps.P) ? prow[(size_t)2 * n_rows] : zero2;
             for (uint32_t p = 0; p < ps.P; ++p) {
                 const float2 d = d0;
                 d0 = d1; d1 = d2;
-                d2 = (valid && p + 3 < ps.P) ? prow[p + 3] : zero2;
+                d2 = (valid && p + 3 < ps.P) ? prow[(size_t)(p + 3) * n_rows] : zero2;
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 if (!__any(has)) continue;
                 float q[3];
@@ -818,6 +944,15 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint3
 
 constexpr int kReduceWaves = 16;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
 
+// A level that received a non-finite gradient: every entry of the bin becomes NaN, so that torch's GradScaler (and
+// anyone reading encoder.params.grad) sees the overflow exactly as it would after the reference's float atomics.
+__device__ __forceinline__ void poison_bin(const GridLevel &L, uint32_t lb, float *__restrict__ grad_table) {
+    const uint32_t e0 = lb * kBinEntries;
+    const uint32_t live = L.size - e0 < kBinEntries ? L.size - e0 : kBinEntries;
+    float *dst = grad_table + ((size_t)L.offset + e0) * 2;
+    for (uint32_t i = threadIdx.x; i < live * 2; i += blockDim.x) dst[i] = __builtin_nanf("");
+}
+
 // Every record value is scaled by a power of two 2^k chosen from the largest |value| any wave emitted for the level
 // (|v| 2^k < 2^38, so 2^24 records cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is
 // exact; what is dropped is whatever lies more than 38 binary digits below the level's largest contribution - far
@@ -845,7 +980,8 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
         // records hold binary16 values pre-scaled by 2^kexp (|v| < 2^15); times 2^24 every binary16 is an exact integer
         int kexp;
         const float amax = level_scale_exp(level_absmax, lvl, kexp);
-        if (!(amax > 0.f) || !(amax < 3.0e38f)) return;
+        if (amax != amax || amax > 3.0e38f) { poison_bin(T.level[lvl], lb, grad_table); return; }
+        if (!(amax > 0.f)) return;
         scale = 16777216.0f;
         unscale = ldexp(1.0, -(24 + kexp));
         __syncthreads();
@@ -858,6 +994,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
         __syncthreads();
         m = 0.f;
         for (int w = 0; w < kReduceWaves; ++w) m = fmaxf(m, wg_max[w]);
+        if (m > 3.0e38f) { poison_bin(T.level[lvl], lb, grad_table); return; }  // an inf / NaN record was emitted
         if (!(m > 0.f)) return;  // nothing but zeros was emitted for this level (uniform across the workgroup)
         int e;
         (void)frexpf(m, &e);  // m < 2^e
@@ -882,7 +1019,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
-                    if (rec[u].y != 0u && !(plan.debug & 1u)) {
+                    if (rec[u].y != 0u) {
                         const uint32_t local = (rec[u].x & (kBinEntries - 1)) * 2;
                         const float g0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec[u].y & 0xFFFFu));
                         const float g1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec[u].y >> 16));
@@ -902,9 +1039,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
-                    if (plan.debug & 1u) {
-                        if (rec[u].g0 == 12345.678f) acc[lane] = 1ull;
-                    } else if (i0 + u * kWave + lane < cnt) {
+                    if (i0 + u * kWave + lane < cnt) {
                         const uint32_t local = (rec[u].entry & (kBinEntries - 1)) * 2;
                         atomicAdd(&acc[local], (unsigned long long)__float2ll_rn(rec[u].g0 * scale));
                         atomicAdd(&acc[local + 1], (unsigned long long)__float2ll_rn(rec[u].g1 * scale));
@@ -934,7 +1069,7 @@ __global__ void k_replica_reduce(const float *__restrict__ rep, uint32_t n_rep, 
     if (s != 0.f) grad_table[i] += s;
 }
 
-static const uint32_t kReplicas = getenv("MI3D_REPLICAS") ? (uint32_t)atoi(getenv("MI3D_REPLICAS")) : 64u;
+constexpr uint32_t kReplicasDefault = 64;  // private table copies of the atomic fallback (same-line serialisation)
 
 }  // namespace
 
@@ -1008,12 +1143,23 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const uint32_t tiles = (n + kTile - 1) / kTile;
+    const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 3);
+    const bool pair = variant & 1, reuse = (variant & 2) && P > 1;
+    EncodePlan plan = make_encode_plan(T, ps, tiles, reuse, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
+    const int rl = MI3D_TUNE(MI3D_T_ENCODE_REUSE_LEVELS, -1);
+    if (rl >= 0) plan.reuse_levels = (uint32_t)rl;
     uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
-    static const uint32_t per_cu = getenv("MI3D_ENCODE_WGS_PER_CU") ? (uint32_t)atoi(getenv("MI3D_ENCODE_WGS_PER_CU")) : 2u;  // measured: 2 -> 39.9 ms, 4 -> 43.0 ms at C2
+    const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 2);  // round 1: 2 -> 39.9 ms, 4 -> 43.0 ms at C2
     const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU
     per_xcd = per_xcd < cap ? per_xcd : cap;
-    hipLaunchKernelGGL(k_grid_encode_planes, dim3(per_xcd * kXcds), dim3(kWave * kWaves), 0, as_stream(stream), ps, n,
-                       reinterpret_cast<const float2 *>(params), T, reinterpret_cast<float2 *>(out_planes));
+    const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
+    const float2 *tab = reinterpret_cast<const float2 *>(params);
+    float2 *out = reinterpret_cast<float2 *>(out_planes);
+    hipStream_t st = as_stream(stream);
+    if (pair && reuse) hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out);
+    else if (pair) hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out);
+    else if (reuse) hipLaunchKernelGGL((k_grid_encode_planes<false, true>), grid, block, 0, st, ps, n, tab, T, plan, out);
+    else hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out);
     return (int)hipGetLastError();
 }
 
@@ -1074,6 +1220,7 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     if (workspace == nullptr || bin_workspace_bytes(plan) > workspace_bytes) {
         // no usable workspace: the atomic kernels, with private copies of the table against same-line serialisation
         // when the caller's scratch at least holds those
+        const uint32_t kReplicas = (uint32_t)MI3D_TUNE(MI3D_T_REPLICAS, kReplicasDefault);
         const size_t rep_bytes = (size_t)kReplicas * T.n_entries * 2 * sizeof(float);
         if (workspace != nullptr && workspace_bytes >= rep_bytes && rep_bytes < ((size_t)2 << 30)) {
             float *rep = reinterpret_cast<float *>(workspace);
@@ -1086,20 +1233,16 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         }
         return launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, grad_params, st, 0xFFFFFFFFu, plane_rows);
     }
-    plan.debug = getenv("MI3D_BIN_DEBUG") ? (uint32_t)atoi(getenv("MI3D_BIN_DEBUG")) : 0u;
     char *arena = reinterpret_cast<char *>(workspace);
     uint32_t *counts = reinterpret_cast<uint32_t *>(arena + plan.total_bytes);
     float *level_max = reinterpret_cast<float *>(counts + plan.total_counts);
     const size_t lds = (size_t)kWaves * plan.n_bins * sizeof(uint32_t);
     const size_t lds_reduce = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_reduce);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_emit16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kEmit16LdsBytes);
-        attr_set = true;
-    }
+    // per call: the attribute is per device and the call is a host-side table write (no static, re-entrant)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_reduce);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_emit16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kEmit16LdsBytes);
     // the fine levels (>= merge_levels) and the coarse ones are two roles of one emit launch; levels stored as 8-byte
     // records go through the staged emit instead
     const uint32_t all = (uint32_t)((1ull << T.n_levels) - 1);
@@ -1112,11 +1255,11 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
         if (plan.half_mask)
             hipLaunchKernelGGL(k_bin_emit16, dim3(half_waves / kWaves), dim3(kWave * kWaves), kEmit16LdsBytes, st, ps, (uint32_t)s0, s1,
-                               dout_planes, plane_rows, T, plan, plan.half_mask, half_waves, level_absmax, arena, counts,
+                               dout_planes, plane_rows, n, T, plan, plan.half_mask, half_waves, level_absmax, arena, counts,
                                grad_params);
         if (fine_waves + coarse_waves)
             hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
-                               (uint32_t)s0, s1, dout_planes, plane_rows, T, plan, merge_levels, fine_mask, fine_waves,
+                               (uint32_t)s0, s1, dout_planes, plane_rows, n, T, plan, merge_levels, fine_mask, fine_waves,
                                coarse_mask, coarse_waves, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
                            counts, level_max, level_absmax, T, plan, grad_params);

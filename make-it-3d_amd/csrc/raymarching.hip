@@ -425,7 +425,7 @@ __global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thr
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 1; }
+int mi3d_abi_version(void) { return 2; }
 const char *mi3d_last_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
 int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,

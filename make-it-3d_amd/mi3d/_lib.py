@@ -42,11 +42,11 @@ _SIGNATURES = {
     "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp, C.c_size_t, vp, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],
-    "mi3d_mlp_forward": [vp, i32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
-    "mi3d_mlp_backward": [vp, i32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_mlp_forward": [vp, u32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
+    "mi3d_mlp_backward": [vp, u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     # Part 5 ------------------------------------------------------------------------------------------
     "mi3d_field_head_forward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
-    "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
 }
 
 
@@ -87,8 +87,22 @@ def call(name, *args):
         raise Mi3dError(f"{name} failed: hipError {err} ({lib().mi3d_last_error_string(err).decode()})")
 
 
-def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def launch(name, t, *args):
+    """`name(*args, stream)` under a device guard for tensor t: the kernel goes to torch's current stream of the
+    device t (and therefore every pointer in args) lives on, whatever torch.cuda.current_device() says."""
+    with torch.cuda.device(t.device):
+        call(name, *args, stream(t))
+
+
+def stream(t=None):
+    """The HIP stream the C ABI launches on: torch's current stream of `t`'s device (of the current device without t)."""
+    dev = t.device if isinstance(t, torch.Tensor) and t.is_cuda else None
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def on(t):
+    """Device guard for a launch whose pointers live on `t`'s device (a model on cuda:1 without set_device)."""
+    return torch.cuda.device(t.device)
 
 
 def ptr(t):

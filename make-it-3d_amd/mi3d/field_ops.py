@@ -1,12 +1,16 @@
-"""The whole field evaluation - stencil-aware hash-grid encode + matrix-core MLP - as ONE autograd node.
+"""The field evaluation - stencil-aware hash-grid encode + matrix-core MLP (+ the field head) - as ONE autograd node.
 
-forward : features = encode(all P stencil points of every sample) -> h = MLP(features)           (2 launches)
-backward: MLP backward (feature gradient written as level-major planes, weight gradients reduced on chip)
-          -> hash-grid gradient scatter: dense levels by merged atomics, hashed levels through the binned
-             record path that avoids global atomics (csrc/hashgrid.hip)                           (2 + 2/slice launches)
-The per-layer composition (grid_ops.encode_points + mlp_ops.fused_mlp) stays available and computes the same thing;
-this node exists because the binned scatter wants the MLP's input gradient in a layout autograd tensors between two
-separate nodes would not carry, and to hold the [m*P, 32] feature matrix once.
+forward : features = encode(all P stencil points of every sample) -> h = MLP(features) -> head      (3 launches)
+backward: head backward -> MLP backward (feature gradient written as level-major planes, weight gradients reduced
+          on chip) -> hash-grid gradient scatter through the binned record path (csrc/hashgrid.hip)
+
+Rows are POINT-MAJOR everywhere (row = p*n + s): the rows of one stencil point are contiguous, so a backward pass
+that reaches only the first P' points of the stencil runs over that prefix and nothing else.  That is what makes the
+reference's two-backward SDS schedule (nerf/sd.py:171 then nerf/utils.py:983) cheap here: its first backward carries a
+gradient for sigma and albedo only (point 0: 1/13 of the rows), its second one for everything; `_Field` reads which
+of its outputs received a gradient (None = none) and sizes the MLP backward and the scatter accordingly.
+
+The per-layer composition (grid_ops.encode_points + mlp_ops.fused_mlp) stays available and computes the same thing.
 """
 import ctypes as C
 import os
@@ -18,42 +22,32 @@ from torch.autograd import Function
 from . import _lib as L
 from . import grid_ops
 
-_WORKSPACE = {}  # device index -> uint8 tensor (record arena of the binned scatter), grown on demand
+# Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples
+# (12 B each: 221 GiB for the 10.9 M samples x 13 points of BASELINE config 2), so samples are processed in slices
+# that fit; 120 GiB lets config 2 go in two.  It is a plain torch allocation made per call: the caching allocator
+# hands the same block back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
+WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "120")) * (1 << 30))
 
 
-def scatter_workspace(device, needed, budget_fraction=0.5):
-    """A cached device scratch buffer of min(needed, budget) bytes.  The budget is a fraction of the memory that is
-    free right now (plus what the cached buffer already holds); MI3D_SCATTER_WORKSPACE_GB overrides it."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    cur = _WORKSPACE.get(idx)
-    have = cur.numel() if cur is not None else 0
-    if have >= needed:
-        return cur
-    env = os.environ.get("MI3D_SCATTER_WORKSPACE_GB")
-    if env is not None:
-        budget = int(float(env) * (1 << 30))
-    else:
-        free, _ = torch.cuda.mem_get_info(idx)
-        budget = int((free + have) * budget_fraction)
-    want = min(int(needed), budget)
-    if want <= have:
-        return cur
-    _WORKSPACE[idx] = None
-    del cur
-    _WORKSPACE[idx] = torch.empty(want, dtype=torch.uint8, device=device) if want > 0 else None
-    return _WORKSPACE[idx]
+def scatter_workspace(device, needed, cap=None):
+    """uint8 scratch of min(needed, cap, 45 % of the device's memory) bytes from torch's caching allocator (or None)."""
+    cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
+    total = torch.cuda.get_device_properties(device).total_memory
+    want = min(int(needed), cap, int(total * 0.45))
+    return torch.empty(want, dtype=torch.uint8, device=device) if want > 0 else None
 
 
 def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None, level_absmax=None):
-    """grad_params [n_params] from level-major feature-gradient planes [L][n*P][2] (C ABI: mi3d_grid_scatter_binned).
-    workspace_bytes: None = cached scratch sized by scatter_workspace; 0 = force the all-atomic path.
+    """grad_params [n_params] from level-major feature-gradient planes [L][P*n][2], rows point-major (C ABI:
+    mi3d_grid_scatter_binned).
+    workspace_bytes: None = scratch sized by scatter_workspace; 0 = force the all-atomic path.
     level_absmax: float32[16] device tensor of per-level max |dplanes| (from the MLP backward) - selects the 8-byte
     binary16 records for the fine levels; None keeps fp32 records everywhere."""
     offs, offs_p = grid_ops._offs_arg(offsets)
     P, n = offs.shape[0], x.shape[0]
     dplanes = L.dev_f32(dplanes, "dplanes")
     if dplanes.numel() != cfg["n_levels"] * n * P * 2:
-        raise L.Mi3dError(f"dplanes has {dplanes.numel()} elements, expected [L={cfg['n_levels']}][{n * P}][2]")
+        raise L.Mi3dError(f"dplanes has {dplanes.numel()} elements, expected [L={cfg['n_levels']}][{P * n}][2]")
     grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
     lib = L.lib()
     ws, ws_bytes = None, 0
@@ -61,20 +55,62 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
         needed = lib.mi3d_grid_scatter_binned_workspace(n, P, float(bound), float(step), cfg["n_levels"],
                                                         cfg["base_resolution"], cfg["per_level_scale"],
                                                         cfg["log2_hashmap_size"], 1 if level_absmax is not None else 0)
-        if workspace_bytes is not None:
-            needed = min(needed, int(workspace_bytes))
-            ws = torch.empty(needed, dtype=torch.uint8, device=x.device) if needed else None
-        elif needed:
-            ws = scatter_workspace(x.device, needed)
+        if needed:
+            ws = scatter_workspace(x.device, needed, workspace_bytes)
         ws_bytes = ws.numel() if ws is not None else 0
-    grid_ops._timed("scatter", lambda: L.call(
-        "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
-        cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-        L.ptr(level_absmax), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream()), n * P)
+    with L.on(x):
+        grid_ops._timed("scatter", lambda: L.call(
+            "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
+            cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
+            L.ptr(level_absmax), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
     return grad
 
 
+# When True (the default) the fine levels of the scatter use 8-byte {entry, binary16 pair} records under
+# torch.autocast(float16) - the upstream feature gradient is binary16 there anyway, but every corner contribution
+# w * dfeature is then ROUNDED to binary16 where tiny-cuda-nn adds the fp32 product (gradients within ~1e-3 of the fp32
+# path instead of ~1e-5).  False keeps 12-byte fp32 records on every level: the like-for-like arithmetic.
+HALF_RECORDS = False
+
+
+def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode):
+    """feats [L][P*n][2] and h [P*n, 4] (point-major rows)."""
+    P, n = offs.shape[0], x.shape[0]
+    feats = torch.empty(cfg["n_levels"], P * n, 2, dtype=torch.float32, device=x.device)
+    grid_ops._timed("encode", lambda: L.call(
+        "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
+        cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(feats),
+        L.stream(x)), n * P)
+    dims = (ws[0].shape[1], ws[0].shape[0], ws[4].shape[0])
+    h = torch.empty(P * n, dims[2], dtype=torch.float32, device=x.device)
+    grid_ops._timed("mlp_fwd", lambda: L.call(
+        "mi3d_mlp_forward", L.ptr(feats), P * n, P * n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h),
+        L.stream(x)), n * P)
+    return feats, h, dims
+
+
+def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step, n_params, half_mode, P_active):
+    """(grad_params, [dW1, db1, dW2, db2, dW3, db3]) from dh [P_active*n, 4]: the MLP backward and the scatter run over
+    the first P_active points of the stencil only."""
+    n = x.shape[0]
+    rows, plane_rows = P_active * n, feats.shape[1]
+    dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
+    grads = [torch.zeros_like(t) for t in ws]
+    # under autocast the feature gradients are binary16-precise: the scatter may then use its 8-byte records,
+    # scaled per level by the maxima the MLP backward collects
+    absmax = (torch.zeros(cfg["n_levels"], dtype=torch.float32, device=x.device)
+              if (half_mode and HALF_RECORDS) else None)
+    grid_ops._timed("mlp_bwd", lambda: L.call(
+        "mi3d_mlp_backward", L.ptr(feats), plane_rows, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, int(half_mode),
+        L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream(x)), rows)
+    gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
+                        n_params, level_absmax=absmax)
+    return gp, grads
+
+
 class _FieldStencil(Function):
+    """h [P*n, 4] = MLP(encode(stencil)); the head stays outside (any P, e.g. the 6-point finite_difference_normal)."""
+
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, params, W1, b1, W2, b2, W3, b3, x, x2, offsets, P0, bound, cfg, step, half_mode):
@@ -84,18 +120,8 @@ class _FieldStencil(Function):
         params = L.dev_f32(params, "params")
         ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
         offs, offs_p = grid_ops._offs_arg(offsets)
-        P, n = offs.shape[0], x.shape[0]
-        # features as level-major planes [L][n*P][2]: written by the per-XCD gather, read as such by both MLP kernels
-        feats = torch.empty(cfg["n_levels"], n * P, 2, dtype=torch.float32, device=x.device)
-        grid_ops._timed("encode", lambda: L.call(
-            "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
-            cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(feats),
-            L.stream()), n * P)
-        dims = (W1.shape[1], W1.shape[0], W3.shape[0])
-        h = torch.empty(n * P, dims[2], dtype=torch.float32, device=x.device)
-        grid_ops._timed("mlp_fwd", lambda: L.call(
-            "mi3d_mlp_forward", L.ptr(feats), 1, n * P, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h),
-            L.stream()), n * P)
+        with L.on(x):
+            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode)
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, *ws)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
                     int(half_mode))
@@ -106,36 +132,68 @@ class _FieldStencil(Function):
     def backward(ctx, dh):
         x, x2, feats, *ws = ctx.saved_tensors
         offs, P0, bound, cfg, step, has_x2, n_params, dims, half_mode = ctx.meta
-        rows = feats.shape[1]
         dh = L.dev_f32(dh.float().contiguous(), "dh", dims[2])
-        dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
-        grads = [torch.zeros_like(t) for t in ws]
-        # under autocast the feature gradients are binary16-precise: the scatter may then use its 8-byte records,
-        # scaled per level by the maxima the MLP backward collects
-        absmax = torch.zeros(cfg["n_levels"], dtype=torch.float32, device=x.device) if half_mode else None
-        grid_ops._timed("mlp_bwd", lambda: L.call(
-            "mi3d_mlp_backward", L.ptr(feats), 1, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, half_mode,
-            L.ptr(dplanes), 1, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream()), rows)
-        gp = scatter_binned(x, x2 if has_x2 else None, offs, P0, bound, dplanes, cfg, step, n_params,
-                            level_absmax=absmax)
+        with L.on(x):
+            gp, grads = _backward_mlp_scatter(dh, feats, ws, dims, x, x2 if has_x2 else None, offs, P0, bound, cfg,
+                                              step, n_params, half_mode, offs.shape[0])
         return (gp, *grads, None, None, None, None, None, None, None, None)
 
 
+def _half_mode(half_mode):
+    if half_mode is None:
+        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+    return bool(half_mode)
+
+
 def field_stencil(params, layers, x, offsets, cfg, bound=1.0, x2=None, P0=None, step=0.0, half_mode=None):
-    """h [n*P, 4] (row = sample*P + point): the MLP output at clamp(base + offsets[p]) for every sample, differentiable
+    """h [P*n, 4] (row = point*n + sample): the MLP output at clamp(base + offsets[p]) for every sample, differentiable
     w.r.t. the hash table and the MLP weights.  `layers`: the three nn.Linear modules of sigma_net."""
     P = np.asarray(offsets).reshape(-1, 3).shape[0]
     if P0 is None:
         P0 = P
-    if half_mode is None:
-        half_mode = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
     l1, l2, l3 = layers
     return _FieldStencil.apply(params, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, x, x2, offsets, P0,
-                               bound, cfg, step, bool(half_mode))
+                               bound, cfg, step, _half_mode(half_mode))
+
+
+def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon):
+    P, n, dev = offs.shape[0], x.shape[0], x.device
+    sigma = torch.empty(n, dtype=torch.float32, device=dev)
+    albedo = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    normal = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    normal2 = torch.empty(n, 3, dtype=torch.float32, device=dev) if P == 13 else None
+    grid_ops._timed("head_fwd", lambda: L.call(
+        "mi3d_field_head_forward", L.ptr(h), L.ptr(x), L.ptr(x2), n, offs_p, P, float(bound), float(blob_density),
+        float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal), L.ptr(normal2),
+        L.stream(x)), n)
+    return sigma, albedo, normal, normal2
+
+
+def _head_backward(h, x, x2, offs, bound, blob_density, blob_radius, epsilon, grads, P_active):
+    """dh [P_active*n, 4] from the upstream gradients (dsigma, dalbedo, dnormal, dnormal2), any of them None."""
+    _, offs_p = grid_ops._offs_arg(offs)
+    n, P = x.shape[0], offs.shape[0]
+    g = [None if t is None else L.dev_f32(t.float().contiguous(), "grad") for t in grads]
+    g += [None] * (4 - len(g))
+    dh = torch.empty(P_active * n, 4, dtype=torch.float32, device=x.device)
+    grid_ops._timed("head_bwd", lambda: L.call(
+        "mi3d_field_head_backward", L.ptr(h), L.ptr(x), L.ptr(x2), n, offs_p, P, int(P_active), float(bound),
+        float(blob_density), float(blob_radius), float(epsilon), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]),
+        L.ptr(dh), L.stream(x)), n)
+    return dh
+
+
+def _active_points(P, grads):
+    """How far into the stencil the upstream gradient reaches: 1 (sigma / albedo only), 7 (normal), 13 (normal2)."""
+    if P == 13 and len(grads) > 3 and grads[3] is not None:
+        return 13
+    if len(grads) > 2 and grads[2] is not None:
+        return 7
+    return 1
 
 
 class _FieldHead(Function):
-    """sigma, albedo, normal(x), normal(x2) from h [n*P, 4] in one elementwise kernel per direction (C ABI Part 5)."""
+    """sigma, albedo, normal(x), normal(x2) from h [P*n, 4] in one elementwise kernel per direction (C ABI Part 5)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -144,20 +202,15 @@ class _FieldHead(Function):
         P = offs.shape[0]
         x = L.dev_f32(x.contiguous().view(-1, 3), "x", 3)
         n = x.shape[0]
-        h = L.dev_f32(h.contiguous().view(n * P, 4), "h", 4)
+        h = L.dev_f32(h.contiguous().view(P * n, 4), "h", 4)
         if x2 is not None:
             x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
-        dev = x.device
-        sigma = torch.empty(n, dtype=torch.float32, device=dev)
-        albedo = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        normal = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        normal2 = torch.empty(n, 3, dtype=torch.float32, device=dev) if P == 13 else None
-        grid_ops._timed("head_fwd", lambda: L.call(
-            "mi3d_field_head_forward", L.ptr(h), L.ptr(x), L.ptr(x2), n, offs_p, P, float(bound), float(blob_density),
-            float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal), L.ptr(normal2),
-            L.stream()), n)
+        with L.on(x):
+            sigma, albedo, normal, normal2 = _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius,
+                                                           epsilon)
         ctx.save_for_backward(h, x, x2 if x2 is not None else x)
-        ctx.meta = (offs, P, float(bound), float(blob_density), float(blob_radius), float(epsilon), x2 is not None)
+        ctx.meta = (offs, float(bound), float(blob_density), float(blob_radius), float(epsilon), x2 is not None)
+        ctx.set_materialize_grads(False)
         if normal2 is None:
             return sigma, albedo, normal
         return sigma, albedo, normal, normal2
@@ -166,19 +219,76 @@ class _FieldHead(Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, *grads):
         h, x, x2 = ctx.saved_tensors
-        offs, P, bound, blob_density, blob_radius, epsilon, has_x2 = ctx.meta
-        _, offs_p = grid_ops._offs_arg(offs)
-        g = [None if t is None else L.dev_f32(t.float().contiguous(), "grad") for t in grads] + [None]
-        dh = torch.empty_like(h)
-        n = x.shape[0]
-        grid_ops._timed("head_bwd", lambda: L.call(
-            "mi3d_field_head_backward", L.ptr(h), L.ptr(x), L.ptr(x2 if has_x2 else None), n, offs_p, P, bound,
-            blob_density, blob_radius, epsilon, L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]), L.ptr(dh),
-            L.stream()), n)
+        offs, bound, blob_density, blob_radius, epsilon, has_x2 = ctx.meta
+        P, n = offs.shape[0], x.shape[0]
+        P_active = _active_points(P, grads)
+        with L.on(x):
+            dh = _head_backward(h, x, x2 if has_x2 else None, offs, bound, blob_density, blob_radius, epsilon, grads,
+                                P_active)
+        if P_active < P:  # autograd wants the full [P*n, 4]: the points beyond the active prefix carry zeros
+            dh = torch.cat([dh, dh.new_zeros((P - P_active) * n, 4)], 0)
         return dh, None, None, None, None, None, None, None
 
 
 def field_head(h, x, offsets, bound, blob_density, blob_radius, x2=None, epsilon=grid_ops.EPS):
-    """(sigma [n], albedo [n,3], normal [n,3], normal_jitter [n,3] or None) from h [n*P, 4]; P must be 7 or 13."""
+    """(sigma [n], albedo [n,3], normal [n,3], normal_jitter [n,3] or None) from h [P*n, 4]; P must be 7 or 13."""
     out = _FieldHead.apply(h, x, x2, offsets, bound, blob_density, blob_radius, epsilon)
+    return out if len(out) == 4 else (*out, None)
+
+
+class _Field(Function):
+    """encode -> MLP -> head as one node (P = 7 or 13).  Its backward looks at WHICH outputs received a gradient and
+    runs head backward, MLP backward and scatter over the reached prefix of the stencil only (module docstring)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, params, W1, b1, W2, b2, W3, b3, x, x2, offsets, P0, bound, cfg, step, half_mode, blob_density,
+                blob_radius, epsilon):
+        x = L.dev_f32(x.contiguous().view(-1, 3), "x", 3)
+        if x2 is not None:
+            x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
+        params = L.dev_f32(params, "params")
+        ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
+        offs, offs_p = grid_ops._offs_arg(offsets)
+        if offs.shape[0] not in (7, 13):
+            raise L.Mi3dError("the fused field takes the 7- or 13-point stencil")
+        with L.on(x):
+            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode)
+            sigma, albedo, normal, normal2 = _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius,
+                                                           epsilon)
+        ctx.save_for_backward(x, x2 if x2 is not None else x, feats, h, *ws)
+        ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
+                    int(half_mode), float(blob_density), float(blob_radius), float(epsilon))
+        ctx.set_materialize_grads(False)
+        if normal2 is None:
+            return sigma, albedo, normal
+        return sigma, albedo, normal, normal2
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, *grads):
+        x, x2, feats, h, *ws = ctx.saved_tensors
+        (offs, P0, bound, cfg, step, has_x2, n_params, dims, half_mode, blob_density, blob_radius,
+         epsilon) = ctx.meta
+        none = (None,) * 18
+        if all(g is None for g in grads):
+            return none
+        P_active = _active_points(offs.shape[0], grads)
+        with L.on(x):
+            dh = _head_backward(h, x, x2 if has_x2 else None, offs, bound, blob_density, blob_radius, epsilon, grads,
+                                P_active)
+            gp, wg = _backward_mlp_scatter(dh, feats, ws, dims, x, x2 if has_x2 else None, offs, P0, bound, cfg, step,
+                                           n_params, half_mode, P_active)
+        return (gp, *wg, *none[:11])
+
+
+def field(params, layers, x, offsets, cfg, bound, blob_density, blob_radius, x2=None, P0=None, step=0.0,
+          half_mode=None, epsilon=grid_ops.EPS):
+    """(sigma [n], albedo [n,3], normal [n,3], normal_jitter [n,3] or None) of the 7- / 13-point stencil, one node."""
+    P = np.asarray(offsets).reshape(-1, 3).shape[0]
+    if P0 is None:
+        P0 = P
+    l1, l2, l3 = layers
+    out = _Field.apply(params, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, x, x2, offsets, P0, bound,
+                       cfg, step, _half_mode(half_mode), blob_density, blob_radius, epsilon)
     return out if len(out) == 4 else (*out, None)

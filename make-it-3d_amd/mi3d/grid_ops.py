@@ -55,10 +55,11 @@ class _EncodePoints(Function):
         out = torch.empty(n * P, cfg["n_levels"] * 2, dtype=torch.float32, device=x.device)
         if count is not None:  # rows past *count are not written by the kernel
             out.zero_()
-        _timed("encode", lambda: L.call(
-            "mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
-            L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"],
-            L.ptr(out), L.stream()), n * P)
+        with L.on(x):
+            _timed("encode", lambda: L.call(
+                "mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
+                L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"],
+                cfg["log2_hashmap_size"], L.ptr(out), L.stream(x)), n * P)
         ctx.save_for_backward(x, x2 if x2 is not None else x, count if count is not None else x)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, count is not None, params.numel())
         return out
@@ -71,17 +72,18 @@ class _EncodePoints(Function):
         dout = L.dev_f32(dout.float().contiguous(), "dout")
         grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
         _, offs_p = _offs_arg(offs)
-        _timed("scatter", lambda: L.call(
-            "mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
-            L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
-            cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad), L.stream()),
-            x.shape[0] * offs.shape[0])
+        with L.on(x):
+            _timed("scatter", lambda: L.call(
+                "mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
+                L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
+                cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad),
+                L.stream(x)), x.shape[0] * offs.shape[0])
         return grad, None, None, None, None, None, None, None, None
 
 
 def encode_points(params, x, offsets, cfg, bound=1.0, x2=None, P0=None, step=0.0, count=None):
-    """features [n*P, 2L] (row = sample*P + point) of clamp(base + offsets[p]) for every sample; differentiable
-    w.r.t. `params`."""
+    """features [P*n, 2L] (point-major: row = point*n + sample) of clamp(base + offsets[p]) for every sample;
+    differentiable w.r.t. `params`."""
     P = np.asarray(offsets).reshape(-1, 3).shape[0]
     if P0 is None:
         P0 = P

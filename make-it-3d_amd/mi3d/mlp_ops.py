@@ -21,8 +21,10 @@ class _FusedMLP(Function):
         n = x.shape[0]
         out = torch.empty(n, W3.shape[0], dtype=torch.float32, device=x.device)
         dims = (W1.shape[1], W1.shape[0], W3.shape[0])
-        grid_ops._timed("mlp_fwd", lambda: L.call(
-            "mi3d_mlp_forward", L.ptr(x), 0, n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out), L.stream()), n)
+        with L.on(x):
+            grid_ops._timed("mlp_fwd", lambda: L.call(
+                "mi3d_mlp_forward", L.ptr(x), 0, n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out),
+                L.stream(x)), n)
         ctx.save_for_backward(x, *ws)
         ctx.meta = (dims, int(half_mode))
         return out
@@ -36,9 +38,10 @@ class _FusedMLP(Function):
         n = x.shape[0]
         dx = torch.empty_like(x)
         grads = [torch.zeros_like(t) for t in ws]
-        grid_ops._timed("mlp_bwd", lambda: L.call(
-            "mi3d_mlp_backward", L.ptr(x), 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
-            0, L.ptr(None), *[L.ptr(g) for g in grads], L.stream()), n)
+        with L.on(x):
+            grid_ops._timed("mlp_bwd", lambda: L.call(
+                "mi3d_mlp_backward", L.ptr(x), 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
+                0, L.ptr(None), *[L.ptr(g) for g in grads], L.stream(x)), n)
         return (dx, *grads, None)
 
 

@@ -6,7 +6,7 @@ state_dict keys (`encoder.params`, `sigma_net.net.{l}.{weight,bias}`), same meth
 (`common_forward / density / normal / finite_difference_normal / forward / gaussian / get_params`).
 The difference is `field_stencil`: the value at x, the six finite-difference neighbours of x and the six
 neighbours of the jittered x2 (13 encoder+MLP passes in the reference) are evaluated - and back-propagated -
-as ONE stencil-aware encode (mi3d.grid_ops) followed by ONE MLP over [m*13, 2L] rows.
+as ONE stencil-aware encode (mi3d.grid_ops) followed by ONE MLP over [13*m, 2L] rows (point-major: row = p*m + s).
 """
 import numpy as np
 import torch
@@ -106,13 +106,15 @@ class NeRFNetwork(NeRFRenderer):
         return self._head(self.sigma_net(self._encode(x, self._CENTER)), x)
 
     def _stencil_sigma(self, x, offsets, x2=None, P0=None, step=0.0):
-        """sigma at clamp(base + offsets[p]) for every sample: [n, P]; plus albedo of point 0."""
+        """sigma at clamp(base + offsets[p]) for every sample: [n, P]; plus the MLP output h [n, P, 4] (a view of the
+        point-major [P, n, 4] the kernels produce)."""
         n, P = x.shape[0], offsets.shape[0]
         if self.sigma_net.fused_ok(x) and self.encoder.cfg["n_levels"] * 2 == self.sigma_net.dim_in:
             h = field_ops.field_stencil(self.encoder.params, self.sigma_net.net, x, offsets, self.encoder.cfg,
-                                        float(self.bound), x2, P0, step).view(n, P, 4)
+                                        float(self.bound), x2, P0, step)
         else:
-            h = self.sigma_net(self._encode(x, offsets, x2, P0, step)).view(n, P, 4)
+            h = self.sigma_net(self._encode(x, offsets, x2, P0, step))
+        h = h.view(P, n, 4).transpose(0, 1)
         offs = torch.from_numpy(offsets).to(x.device)
         base = x.unsqueeze(1).expand(n, P, 3)
         if x2 is not None:
@@ -143,10 +145,10 @@ class NeRFNetwork(NeRFRenderer):
         x = x.reshape(-1, 3).float()
         offs, P0 = grid_ops.stencil_offsets(center=True, second=x2 is not None)
         if x.is_cuda and self.sigma_net.fused_ok(x) and self.encoder.cfg["n_levels"] * 2 == self.sigma_net.dim_in:
-            # one node for encode + MLP, one for the whole head (sigma, albedo, both finite-difference normals)
-            h = field_ops.field_stencil(self.encoder.params, self.sigma_net.net, x, offs, self.encoder.cfg,
-                                        float(self.bound), x2, P0 if x2 is not None else None, step)
-            return field_ops.field_head(h, x, offs, float(self.bound), self.opt.blob_density, self.opt.blob_radius, x2)
+            # ONE node for encode + MLP + head (sigma, albedo, both finite-difference normals); its backward runs over
+            # the stencil points the upstream gradient actually reaches (field_ops._Field)
+            return field_ops.field(self.encoder.params, self.sigma_net.net, x, offs, self.encoder.cfg, float(self.bound),
+                                   self.opt.blob_density, self.opt.blob_radius, x2, P0 if x2 is not None else None, step)
         sig, h = self._stencil_sigma(x, offs, x2, P0 if x2 is not None else None, step)
         albedo = torch.sigmoid(h[:, 0, 1:])
         normals = self._normal_from(sig[:, 1:7])

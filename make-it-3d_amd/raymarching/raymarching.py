@@ -60,8 +60,8 @@ class _near_far_from_aabb(Function):
         N = rays_o.shape[0]
         nears = torch.empty(N, dtype=_f32, device=rays_o.device)
         fars = torch.empty(N, dtype=_f32, device=rays_o.device)
-        L.call("mi3d_near_far_from_aabb", L.ptr(rays_o), L.ptr(rays_d), L.ptr(aabb), N, float(min_near),
-               L.ptr(nears), L.ptr(fars), L.stream())
+        L.launch("mi3d_near_far_from_aabb", rays_o, L.ptr(rays_o), L.ptr(rays_d), L.ptr(aabb), N, float(min_near),
+               L.ptr(nears), L.ptr(fars))
         return nears, fars
 
 
@@ -76,7 +76,7 @@ class _sph_from_ray(Function):
         rays_o, rays_d = _rays(rays_o, rays_d)
         N = rays_o.shape[0]
         coords = torch.empty(N, 2, dtype=_f32, device=rays_o.device)
-        L.call("mi3d_sph_from_ray", L.ptr(rays_o), L.ptr(rays_d), float(radius), N, L.ptr(coords), L.stream())
+        L.launch("mi3d_sph_from_ray", rays_o, L.ptr(rays_o), L.ptr(rays_d), float(radius), N, L.ptr(coords))
         return coords
 
 
@@ -92,7 +92,7 @@ class _morton3D(Function):
         coords = coords.int().contiguous()
         N = coords.shape[0]
         indices = torch.empty(N, dtype=torch.int32, device=coords.device)
-        L.call("mi3d_morton3D", L.ptr(coords), N, L.ptr(indices), L.stream())
+        L.launch("mi3d_morton3D", coords, L.ptr(coords), N, L.ptr(indices))
         return indices
 
 
@@ -108,7 +108,7 @@ class _morton3D_invert(Function):
         indices = indices.int().contiguous()
         N = indices.shape[0]
         coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
-        L.call("mi3d_morton3D_invert", L.ptr(indices), N, L.ptr(coords), L.stream())
+        L.launch("mi3d_morton3D_invert", indices, L.ptr(indices), N, L.ptr(coords))
         return coords
 
 
@@ -128,7 +128,7 @@ class _packbits(Function):
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
         L.dev_typed(bitfield, "bitfield", torch.uint8)
-        L.call("mi3d_packbits", L.ptr(grid), N, float(thresh), L.ptr(bitfield), L.stream())
+        L.launch("mi3d_packbits", grid, L.ptr(grid), N, float(thresh), L.ptr(bitfield))
         return bitfield
 
 
@@ -172,13 +172,12 @@ class _march_rays_train(Function):
         nears, fars = L.dev_f32(nears.contiguous(), "nears"), L.dev_f32(fars.contiguous(), "fars")
         noises = torch.rand(N, dtype=_f32, device=dev) if perturb else torch.zeros(N, dtype=_f32, device=dev)
 
-        L.call("mi3d_march_rays_train", L.ptr(rays_o), L.ptr(rays_d), L.ptr(bits), float(bound), float(dt_gamma),
+        L.launch("mi3d_march_rays_train", rays_o, L.ptr(rays_o), L.ptr(rays_d), L.ptr(bits), float(bound), float(dt_gamma),
                int(max_steps), N, int(C), int(H), M, L.ptr(nears), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs),
-               L.ptr(deltas), L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.stream())
+               L.ptr(deltas), L.ptr(rays), L.ptr(step_counter), L.ptr(noises))
         if exact:
             a = align if align > 0 else 1
-            L.call("mi3d_march_zero_tail", L.ptr(step_counter), a, M, L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
-                   L.stream())
+            L.launch("mi3d_march_zero_tail", xyzs, L.ptr(step_counter), a, M, L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas))
             m = int(step_counter[0].item())  # the op's contract returns sliced tensors: one D2H sync
             if align > 0:
                 m += align - m % align
@@ -206,8 +205,8 @@ def _composite_train_cls(fwd_name, bwd_name):
             weights_sum = torch.empty(N, dtype=_f32, device=dev)
             depth = torch.empty(N, dtype=_f32, device=dev)
             image = torch.empty(N, 3, dtype=_f32, device=dev)
-            L.call(fwd_name, L.ptr(sigmas), L.ptr(rgbs), L.ptr(deltas), L.ptr(rays), M, N, float(T_thresh),
-                   L.ptr(weights_sum), L.ptr(depth), L.ptr(image), L.stream())
+            L.launch(fwd_name, sigmas, L.ptr(sigmas), L.ptr(rgbs), L.ptr(deltas), L.ptr(rays), M, N, float(T_thresh),
+                   L.ptr(weights_sum), L.ptr(depth), L.ptr(image))
             ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
             ctx.dims = [M, N, T_thresh]
             return weights_sum, depth, image
@@ -222,9 +221,9 @@ def _composite_train_cls(fwd_name, bwd_name):
             M, N, T_thresh = ctx.dims
             grad_sigmas = torch.zeros_like(sigmas)  # samples past a ray's termination keep zero gradient
             grad_rgbs = torch.zeros_like(rgbs)
-            L.call(bwd_name, L.ptr(grad_weights_sum), L.ptr(grad_image), L.ptr(sigmas), L.ptr(rgbs), L.ptr(deltas),
+            L.launch(bwd_name, sigmas, L.ptr(grad_weights_sum), L.ptr(grad_image), L.ptr(sigmas), L.ptr(rgbs), L.ptr(deltas),
                    L.ptr(rays), L.ptr(weights_sum), L.ptr(image), M, N, float(T_thresh), L.ptr(grad_sigmas),
-                   L.ptr(grad_rgbs), L.stream())
+                   L.ptr(grad_rgbs))
             return grad_sigmas, grad_rgbs, None, None, None
 
     return _composite
@@ -256,10 +255,10 @@ class _march_rays(Function):
         deltas = torch.zeros(M, 2, dtype=_f32, device=dev)
         noises = (torch.rand if perturb else torch.zeros)(n_alive, dtype=_f32, device=dev)
         bits = L.dev_typed(density_bitfield.contiguous(), "density_bitfield", torch.uint8)
-        L.call("mi3d_march_rays", int(n_alive), int(n_step), L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)),
+        L.launch("mi3d_march_rays", rays_o, int(n_alive), int(n_step), L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)),
                L.ptr(L.dev_f32(rays_t, "rays_t")), L.ptr(rays_o), L.ptr(rays_d), float(bound), float(dt_gamma),
                int(max_steps), int(C), int(H), L.ptr(bits), L.ptr(L.dev_f32(near, "near")),
-               L.ptr(L.dev_f32(far, "far")), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas), L.ptr(noises), L.stream())
+               L.ptr(L.dev_f32(far, "far")), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas), L.ptr(noises))
         return xyzs, dirs, deltas
 
 
@@ -275,11 +274,11 @@ class _composite_rays(Function):
         sigmas = L.dev_f32(sigmas.float().contiguous(), "sigmas")
         rgbs = L.dev_f32(rgbs.float().contiguous(), "rgbs")
         normals = L.dev_f32(normals.float().contiguous(), "normals")
-        L.call("mi3d_composite_rays", int(n_alive), int(n_step), float(T_thresh),
+        L.launch("mi3d_composite_rays", sigmas, int(n_alive), int(n_step), float(T_thresh),
                L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")),
                L.ptr(sigmas), L.ptr(rgbs), L.ptr(normals), L.ptr(L.dev_f32(deltas, "deltas")),
                L.ptr(L.dev_f32(weights_sum, "weights_sum")), L.ptr(L.dev_f32(depth, "depth")),
-               L.ptr(L.dev_f32(image, "image")), L.ptr(L.dev_f32(normal, "normal")), L.stream())
+               L.ptr(L.dev_f32(image, "image")), L.ptr(L.dev_f32(normal, "normal")))
         return tuple()
 
 
@@ -293,11 +292,11 @@ class _composite_sdf_rays(Function):
                 T_thresh=1e-2):
         sigmas = L.dev_f32(sigmas.float().contiguous(), "sigmas")
         rgbs = L.dev_f32(rgbs.float().contiguous(), "rgbs")
-        L.call("mi3d_composite_sdf_rays", int(n_alive), int(n_step), float(T_thresh),
+        L.launch("mi3d_composite_sdf_rays", sigmas, int(n_alive), int(n_step), float(T_thresh),
                L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")),
                L.ptr(sigmas), L.ptr(rgbs), L.ptr(L.dev_f32(deltas, "deltas")),
                L.ptr(L.dev_f32(weights_sum, "weights_sum")), L.ptr(L.dev_f32(depth, "depth")),
-               L.ptr(L.dev_f32(image, "image")), L.stream())
+               L.ptr(L.dev_f32(image, "image")))
         return tuple()
 
 

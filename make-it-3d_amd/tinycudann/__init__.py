@@ -27,8 +27,8 @@ class _hashgrid(Function):
         params = L.dev_f32(params, "params")
         n = x.shape[0]
         out = torch.empty(n, cfg["n_levels"] * 2, dtype=torch.float32, device=x.device)
-        L.call("mi3d_hashgrid_forward", L.ptr(x), n, L.ptr(params), cfg["n_levels"], cfg["base_resolution"],
-               cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(out), L.stream())
+        L.launch("mi3d_hashgrid_forward", x, L.ptr(x), n, L.ptr(params), cfg["n_levels"], cfg["base_resolution"],
+               cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(out))
         ctx.save_for_backward(x)
         ctx.cfg, ctx.n_params = cfg, params.numel()
         return out
@@ -40,8 +40,8 @@ class _hashgrid(Function):
         cfg = ctx.cfg
         dout = L.dev_f32(dout.float().contiguous(), "dout")
         grad = torch.zeros(ctx.n_params, dtype=torch.float32, device=x.device)
-        L.call("mi3d_hashgrid_backward", L.ptr(x), x.shape[0], L.ptr(dout), cfg["n_levels"], cfg["base_resolution"],
-               cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(grad), L.stream())
+        L.launch("mi3d_hashgrid_backward", x, L.ptr(x), x.shape[0], L.ptr(dout), cfg["n_levels"], cfg["base_resolution"],
+               cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(grad))
         return None, grad, None  # no gradient w.r.t. the input positions (the reference never asks for it)
 
 

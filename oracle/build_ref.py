@@ -20,11 +20,33 @@ OUT_DIR = os.path.join(HERE, "_ref")
 OUT = os.path.join(OUT_DIR, "_raymarching_ref.so")
 SRC = "/root/reference/raymarching/src"
 FILES = ("raymarching.cu", "raymarching.h", "bindings.cpp")
+# The reference's own Python for the path (renderer + field + their helpers; optimizer.py for the Adan pin), staged
+# verbatim into the git-ignored oracle/_ref/py/ so the GPU box - which has no /root/reference - can run the reference's
+# NeRFNetwork / NeRFRenderer on the drop-in packages (oracle/ref_import.py).  Never committed, never imported by
+# the product.
+PY_ROOT = "/root/reference"
+PY_FILES = ("nerf/renderer.py", "nerf/network_tcnn.py", "nerf/utils.py", "nerf/refine_utils.py", "nerf/unet.py",
+            "nerf/provider.py", "activation.py", "encoding.py", "optimizer.py")
+PY_OUT = os.path.join(OUT_DIR, "py")
+
+
+def stage_py(force=False):
+    if not os.path.isdir(PY_ROOT):
+        raise RuntimeError(f"{PY_ROOT} not present (the reference tree exists only in the build container)")
+    for rel in PY_FILES:
+        src, dst = os.path.join(PY_ROOT, rel), os.path.join(PY_OUT, rel)
+        if os.path.exists(dst) and not force and os.path.getmtime(dst) >= os.path.getmtime(src):
+            continue
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(src, dst)
+    return PY_OUT
+
 
 
 def build(force=False):
     if not os.path.isdir(SRC):
         raise RuntimeError(f"{SRC} not present (the reference tree exists only in the build container)")
+    stage_py(force)
     if os.path.exists(OUT) and not force:
         return OUT
     os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")

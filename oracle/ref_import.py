@@ -1,22 +1,31 @@
 """ORACLE tooling (test infrastructure, NOT product code).
 
-Imports the reference's *own* Python modules from /root/reference in THIS container so the
-oracle can be pinned against them and golden vectors generated (tests/golden/make_golden_py.py).
-/root/reference does not exist on the GPU box: nothing that runs there may import this module.
+Imports the reference's *own* Python modules so the oracle and the product can be pinned against them:
+  * in the build container from /root/reference (also used to generate tests/golden/*.npz, make_golden_py.py);
+  * on the GPU box - where /root/reference does not exist - from oracle/_ref/py/, a git-ignored staging copy of
+    the handful of reference files the path needs, made by oracle/build_ref.py:stage_py() and shipped by gpurun like
+    oracle/_ref/_raymarching_ref.so.  Nothing is copied into the repository history.
 
-The reference's import-time-only dependencies that are absent from the image (cv2, trimesh,
-open3d, mcubes, imageio, tensorboardX, torchvision, pytorch3d, torch_ema, clip, torchmetrics,
-contextual_loss, ...) are replaced by inert stub modules; `tinycudann` is replaced by a stub whose
-`Encoding` is oracle.field_torch.HashGridTorch (tcnn is CUDA-only and un-pinned: PARITY UNPINNED),
-and `raymarching` by an empty module (the CUDA extension cannot be built without nvcc).
+The reference's import-time-only dependencies that are absent from the image (cv2, trimesh, open3d, mcubes,
+imageio, tensorboardX, torchvision, pytorch3d, torch_ema, clip, torchmetrics, contextual_loss, ...) are replaced
+by inert stub modules.  Two ways to give the reference its `tinycudann` / `raymarching`:
+  encoder="oracle" : tcnn.Encoding = oracle.field_torch.HashGridTorch, a CPU torch restatement (tcnn is CUDA-only and
+                     un-pinned: PARITY UNPINNED); `raymarching` is whatever imports (never called on this route);
+  encoder="dropin" : the product's drop-in packages make-it-3d_amd/{tinycudann, raymarching} - the reference's
+                     NeRFNetwork / NeRFRenderer.run_cuda / update_extra_state then run UNCHANGED on the HIP kernels
+                     (the zero-change route).  tests/test_reference_glue_gpu.py compares
+                     that against the product's own fast route; bench.py times it as the reference-shaped baseline.
 """
+import importlib
 import importlib.abc
 import importlib.machinery
 import os
 import sys
 import types
 
-REFERENCE = "/root/reference"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGED = os.path.join(_HERE, "_ref", "py")
+REFERENCE = "/root/reference" if os.path.isdir("/root/reference/nerf") else STAGED
 
 _STUB_ROOTS = ("cv2", "trimesh", "open3d", "mcubes", "imageio", "tensorboardX", "torchvision", "pytorch3d",
                "torch_ema", "clip", "torchmetrics", "contextual_loss", "rich", "tqdm", "pandas", "matplotlib",
@@ -70,6 +79,7 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 
 
 _installed = False
+TCNN_ORACLE = None  # the stub `tinycudann` module whose Encoding is the CPU torch restatement
 
 
 def available():
@@ -78,18 +88,19 @@ def available():
 
 def install():
     """Make `import nerf.renderer`, `import nerf.network_tcnn`, `import activation` resolve to the reference."""
-    global _installed
+    global _installed, TCNN_ORACLE, _STUB_ROOTS
     if _installed:
         return
     if not available():
-        raise RuntimeError("reference tree not present (expected on the GPU box)")
+        raise RuntimeError(f"reference sources not found (neither /root/reference nor {STAGED}: run "
+                           "oracle/build_ref.py in the build container)")
     sys.dont_write_bytecode = True  # never write .pyc into the read-only reference tree
-    # real scipy / tqdm etc. are fine if importable; only stub what is missing
+    # real scipy / tqdm etc. are fine if importable; only stub what is missing.  `raymarching` resolves to the
+    # product's drop-in package when make-it-3d_amd is on sys.path (tests/conftest.py, bench.py put it there).
     import importlib.util as iu
-    global _STUB_ROOTS
     keep = []
     for r in _STUB_ROOTS:
-        if r in ("raymarching", "clip"):
+        if r == "clip":
             keep.append(r)
             continue
         try:
@@ -102,7 +113,7 @@ def install():
 
     from oracle import field_torch, oracle as O
 
-    tcnn = types.ModuleType("tinycudann")
+    tcnn = types.ModuleType("tinycudann_oracle")
 
     def Encoding(n_input_dims, encoding_config, dtype=None, seed=1337):
         assert n_input_dims == 3 and encoding_config["otype"] == "HashGrid"
@@ -114,9 +125,41 @@ def install():
         return field_torch.HashGridTorch(cfg)
 
     tcnn.Encoding = Encoding
-    sys.modules["tinycudann"] = tcnn
+    TCNN_ORACLE = tcnn
+    try:
+        have_dropin = iu.find_spec("tinycudann") is not None
+    except (ImportError, ValueError):
+        have_dropin = False
+    if not have_dropin:
+        sys.modules["tinycudann"] = tcnn
+    # the reference tree has its own raymarching/ package (CUDA JIT build): make sure the name is already bound - to
+    # the product's drop-in if importable, else to a stub - before the reference root goes first on sys.path
+    if "raymarching" not in sys.modules:
+        try:
+            importlib.import_module("raymarching")
+        except Exception:
+            _STUB_ROOTS = _STUB_ROOTS + ("raymarching",)
+            importlib.import_module("raymarching")
     sys.path.insert(0, REFERENCE)
     _installed = True
+
+
+def reference_network(opt, encoder="oracle", **kw):
+    """The reference's own nerf.network_tcnn.NeRFNetwork(opt, **kw) with its `tcnn` bound to the CPU restatement
+    ("oracle") or to the product's drop-in tinycudann ("dropin")."""
+    install()
+    import nerf.network_tcnn as ref_net
+    if encoder == "oracle":
+        ref_net.tcnn = TCNN_ORACLE
+    elif encoder == "dropin":
+        import raymarching
+        import tinycudann
+        import nerf.renderer as ref_renderer
+        ref_net.tcnn = tinycudann
+        ref_renderer.raymarching = raymarching
+    else:
+        raise ValueError(encoder)
+    return ref_net.NeRFNetwork(opt, **kw)
 
 
 def default_opt(**over):

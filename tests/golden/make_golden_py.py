@@ -54,7 +54,7 @@ def main():
     # ---------------------------------------------------------------- field head
     cfg = O.GridConfig()
     fp = lively_field(cfg, 3, 64, seed=11, table_scale=0.3)
-    net = NeRFNetwork(ref_import.default_opt())
+    net = ref_import.reference_network(ref_import.default_opt())
     load_into_reference(net, fp)
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (192, 3)).astype(np.float32)
@@ -93,7 +93,7 @@ def main():
     # ---------------------------------------------------------------- C1 run()
     c1 = O.GridConfig(n_levels=4, per_level_scale=128 ** (1 / 3))
     fp1 = lively_field(c1, 2, 32, seed=21, table_scale=0.3)
-    net1 = NeRFNetwork(ref_import.default_opt(), num_layers=2, hidden_dim=32)
+    net1 = ref_import.reference_network(ref_import.default_opt(), num_layers=2, hidden_dim=32)
     net1.encoder = HashGridTorch(c1)
     net1.sigma_net = MLP(c1.n_output_dims, 4, 32, 2, bias=True)
     load_into_reference(net1, fp1)

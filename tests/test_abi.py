@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 19
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.mi3d_abi_version() == 1
+    assert lib.mi3d_abi_version() == 2
 
 
 def test_python_binding_covers_the_abi():
@@ -73,3 +73,15 @@ def test_scatter_workspace_query_is_host_only_and_sane():
     # levels 8..15 emit 8 records of 8 bytes per (evaluation, level) in the binary16 layout
     assert full16 > 10_878_592 * 13 * 8 * 8 * 8
     assert full32 < 300e9 and ws(0, *args, 0) == 0
+
+
+def test_product_library_reads_no_environment_and_has_no_dev_hooks():
+    """Hygiene: libmi3d.so imports neither getenv nor the development tunables (those exist only in the -DMI3D_DEV
+    build of tools/build_dev.py), and the kernels carry no debug sentinels."""
+    import subprocess
+    so = os.path.join(PKG, "csrc", "libmi3d.so")
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms and "mi3d_dev_" not in syms
+    for f in ("hashgrid.hip", "field.hip", "raymarching.hip"):
+        src = open(os.path.join(PKG, "csrc", f)).read()
+        assert "getenv" not in src and "12345" not in src and "static bool" not in src, f

@@ -50,26 +50,19 @@ def test_encode_points_matches_pointwise_oracle(cuda, oracle, bound, second):
     offs, P0 = grid_ops.stencil_offsets(center=True, second=second)
     params = rng.uniform(-1, 1, cfg.n_params).astype(np.float32)
     out = grid_ops.encode_points(T(params, cuda), T(x, cuda), offs, kcfg, bound, T(x2, cuda) if second else None,
-                                 P0).cpu().numpy().reshape(n, offs.shape[0], -1)
+                                 P0).cpu().numpy().reshape(offs.shape[0], n, -1)   # rows are point-major: p*n + s
     for p, pts in enumerate(_points(x, x2, offs, P0, bound)):
         h01 = ((pts + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
         ref = oracle.hashgrid_forward(h01, params, cfg)
-        np.testing.assert_allclose(out[:, p], ref, rtol=1e-5, atol=1e-6, err_msg=f"point {p}")
+        np.testing.assert_allclose(out[p], ref, rtol=1e-5, atol=1e-6, err_msg=f"point {p}")
 
 
-@pytest.mark.parametrize("force_scatter", [None, 0, 16])
+@pytest.mark.parametrize("step", [0.0034, 100.0, 1e-7])
 @pytest.mark.parametrize("second", [False, True])
-def test_scatter_points_matches_pointwise_oracle(cuda, oracle, second, force_scatter, monkeypatch):
-    """Backward of the stencil encode == sum of the oracle's per-point backward passes, for every merge regime."""
-    import subprocess, sys, os, json
-    if force_scatter is not None:
-        # the A/B switch is read once per process: run this case in a child process
-        env = dict(os.environ, MI3D_SCATTER=str(force_scatter), MI3D_CHILD="1")
-        code = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
-                               f"test_scatter_points_matches_pointwise_oracle and None and {second}"], env=env,
-                              capture_output=True, text=True)
-        assert code.returncode == 0, code.stdout[-2000:]
-        return
+def test_scatter_points_matches_pointwise_oracle(cuda, oracle, second, step):
+    """Backward of the stencil encode == sum of the oracle's per-point backward passes, for every merge regime: `step`
+    only steers which levels sum equal-cell runs before their atomics (0.0034: levels 0-7, 100: none, 1e-7: all 16),
+    never the result."""
     from mi3d import grid_ops
     rng = np.random.default_rng(4)
     bound = 1.0
@@ -87,8 +80,8 @@ def test_scatter_points_matches_pointwise_oracle(cuda, oracle, second, force_sca
     dout[:, 2, 4:6] = 0
     params = torch.zeros(cfg.n_params, device=cuda, requires_grad=True)
     feats = grid_ops.encode_points(params, T(x, cuda), offs, kcfg, bound, T(x2, cuda) if second else None, P0,
-                                   step=0.0034)
-    feats.backward(T(dout.reshape(n * P, 32), cuda))
+                                   step=step)
+    feats.backward(T(dout.transpose(1, 0, 2).reshape(P * n, 32), cuda))   # point-major rows
     g = params.grad.cpu().numpy()
     ref = np.zeros(cfg.n_params, np.float64)
     for p, pts in enumerate(_points(x, x2, offs, P0, bound)):
@@ -112,11 +105,13 @@ def test_count_caps_rows_without_host_sync(cuda, oracle):
     full = grid_ops.encode_points(params.detach(), T(x, cuda), offs, kcfg)
     part = grid_ops.encode_points(params, T(x, cuda), offs, kcfg, count=count)
     P = offs.shape[0]
-    assert torch.equal(part[:keep * P], full[:keep * P]) and float(part[keep * P:].abs().max()) == 0
+    part_v, full_v = part.view(P, n, -1), full.view(P, n, -1)   # the row stride between points stays n
+    assert torch.equal(part_v[:, :keep], full_v[:, :keep]) and float(part_v[:, keep:].abs().max()) == 0
     part.sum().backward()
     g_part = params.grad.clone()
     params.grad = None
     p2 = grid_ops.encode_points(params, T(x[:keep], cuda), offs, kcfg)
+    assert torch.equal(p2.view(P, keep, -1), full_v[:, :keep])
     p2.sum().backward()
     assert torch.allclose(g_part, params.grad, rtol=1e-5, atol=1e-6)
 
@@ -141,7 +136,7 @@ def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace
     dout = rng.normal(size=(n, P, 16, 2)).astype(np.float32)
     dout[100:140] = 0
     dout[:, 2, 2] = 0
-    planes = np.ascontiguousarray(dout.reshape(n * P, 16, 2).transpose(1, 0, 2))  # [L][rows][2]
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))  # [L][p*n + s][2]
     full = None
     ws = {"auto": None, "none": 0}.get(workspace, "tiny")
     if ws == "tiny":  # room for about a third of the samples per slice
@@ -208,7 +203,7 @@ def test_binned_scatter_half_records_match_oracle(cuda, oracle, workspace):
     mag = (10.0 ** rng.uniform(-8, 4, 16)).astype(np.float32)
     dout = (rng.normal(size=(n, P, 16, 2)).astype(np.float32) * mag[None, None, :, None]).astype(np.float32)
     dout[100:140] = 0
-    planes = np.ascontiguousarray(dout.reshape(n * P, 16, 2).transpose(1, 0, 2))
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
     absmax = T(np.abs(planes).reshape(16, -1).max(1).astype(np.float32), cuda)
     ws = None
     if workspace == "tiny":
@@ -241,7 +236,7 @@ def test_binned_scatter_half_records_axis_parallel_rays(cuda, oracle):
     offs, P0 = grid_ops.stencil_offsets(center=True, second=False)
     P = offs.shape[0]
     dout = rng.normal(size=(n, P, 16, 2)).astype(np.float32)
-    planes = np.ascontiguousarray(dout.reshape(n * P, 16, 2).transpose(1, 0, 2))
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
     absmax = T(np.abs(planes).reshape(16, -1).max(1).astype(np.float32), cuda)
     g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params,
                                  level_absmax=absmax).cpu().numpy()
@@ -253,3 +248,77 @@ def test_binned_scatter_half_records_axis_parallel_rays(cuda, oracle):
         a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
         scale = np.abs(ref[a:b]).max()
         assert np.abs(g[a:b] - ref[a:b]).max() <= (2e-5 if l < 8 else 2e-3) * scale + 1e-30, l
+
+
+@pytest.mark.parametrize("bad", ["inf", "nan"])
+@pytest.mark.parametrize("half", [False, True])
+def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad, half):
+    """A non-finite feature gradient must reach encoder.params.grad (GradScaler's overflow check reads it there): the
+    reference's float atomics would put the inf / NaN into the table; the record path poisons the whole level with NaN
+    and leaves the other levels exact."""
+    from mi3d import field_ops, grid_ops
+    rng = np.random.default_rng(41)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=16, base_resolution=16, per_level_scale=cfg.per_level_scale, log2_hashmap_size=19)
+    n = 2000
+    x = _ray_like_points(rng, n, 1.0)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=False)
+    P = offs.shape[0]
+    dout = rng.normal(size=(n, P, 16, 2)).astype(np.float32)
+    clean = dout.copy()
+    for lvl in (3, 12):   # one run-merged coarse level, one fine level
+        dout[777, 2, lvl, 1] = np.inf if bad == "inf" else np.nan
+    planes = T(np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2)), cuda)
+    absmax = None
+    if half:   # what mi3d_mlp_backward writes: +inf for a level holding a non-finite value
+        a = planes.abs().amax(dim=(1, 2))
+        absmax = torch.where(torch.isfinite(a), a, torch.full_like(a, float("inf"))).contiguous()
+    g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, planes, kcfg, 0.0034, cfg.n_params,
+                                 level_absmax=absmax).cpu().numpy()
+    ref = np.zeros(cfg.n_params, np.float64)
+    for p, pts in enumerate(_points(x, x, offs, P0, 1.0)):
+        ref += oracle.hashgrid_backward(((pts + np.float32(1.0)) / np.float32(2.0)).astype(np.float32),
+                                        clean[:, p].reshape(n, 32), cfg)
+    for l in range(16):
+        a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
+        if l in (3, 12):
+            assert not np.isfinite(g[a:b]).all(), l
+        else:
+            tol = 2e-3 if (half and l >= 8) else 2e-5
+            assert np.isfinite(g[a:b]).all() and np.abs(g[a:b] - ref[a:b]).max() <= tol * np.abs(ref[a:b]).max(), l
+
+
+@pytest.mark.parametrize("reach", [1, 7, 13])
+def test_fused_field_node_runs_only_the_reached_stencil_prefix(cuda, oracle, reach):
+    """field_ops.field (encode + MLP + head, one node) against field_stencil + field_head (two nodes, dense dh) when
+    the upstream gradient reaches only sigma / albedo (point 0), the normal as well (points 0-6) or everything: same
+    outputs, same parameter gradients - the fused node runs MLP backward and scatter over the reached prefix only."""
+    from mi3d import field_ops, grid_ops
+    from mi3d.network import MLP
+    rng = np.random.default_rng(51)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=16, base_resolution=16, per_level_scale=cfg.per_level_scale, log2_hashmap_size=19)
+    n = 3000
+    x = T(_ray_like_points(rng, n, 1.0), cuda)
+    x2 = x + torch.randn_like(x) * 0.01
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    torch.manual_seed(1)
+    mlp = MLP(32, 4, 64, 3).to(cuda)
+    table = torch.empty(cfg.n_params, device=cuda).uniform_(-0.5, 0.5)
+    gs = [torch.randn(n, device=cuda), torch.randn(n, 3, device=cuda), torch.randn(n, 3, device=cuda),
+          torch.randn(n, 3, device=cuda)]
+    outs = []
+    for fused in (True, False):
+        params = table.clone().requires_grad_(True)
+        mlp.zero_grad()
+        if fused:
+            o = field_ops.field(params, mlp.net, x, offs, kcfg, 1.0, 5.0, 0.1, x2, P0, step=0.0034, half_mode=False)
+        else:
+            h = field_ops.field_stencil(params, mlp.net, x, offs, kcfg, 1.0, x2, P0, step=0.0034, half_mode=False)
+            o = field_ops.field_head(h, x, offs, 1.0, 5.0, 0.1, x2)
+        k = {1: 2, 7: 3, 13: 4}[reach]
+        torch.autograd.backward(list(o[:k]), gs[:k])
+        outs.append([t.detach().clone() for t in o] + [params.grad.clone()] + [p.grad.clone() for p in mlp.parameters()])
+    for a, b in zip(*outs):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale

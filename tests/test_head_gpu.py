@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def _torch_head(h, x, x2, offs, bound, density, radius, eps=1e-2):
     n, P = x.shape[0], offs.shape[0]
-    h = h.view(n, P, 4)
+    h = h.view(P, n, 4).transpose(0, 1)   # rows are point-major: p*n + s
     o = torch.from_numpy(offs).to(x.device)
     base = x.unsqueeze(1).expand(n, P, 3)
     if x2 is not None:
@@ -43,7 +43,7 @@ def test_head_matches_torch_composition(cuda, second):
     x[50:60] = 1.0           # stencil clamps at the box
     x2 = (x + torch.randn_like(x) * 0.01) if second else None
     h = (torch.randn(n * P, 4, device=cuda) * 0.5)
-    hv = h.view(n, P, 4)
+    hv = h.view(P, n, 4).transpose(0, 1)
     hv[100:200, 1:, 0] = hv[100:200, 1:2, 0]   # identical neighbours: zero finite difference -> clamp regime
     hv[200:210, :, 0] = 30.0                  # beyond trunc_exp's derivative clamp
     hv[:, 1:7, 0] = hv[:, 1:7, 0] * 0.01 + hv[:, :1, 0]   # neighbours close to the centre value
@@ -60,7 +60,7 @@ def test_head_matches_torch_composition(cuda, second):
     gs = [torch.randn_like(t) for t in want]
     torch.autograd.backward(got, gs)
     torch.autograd.backward(want, gs)
-    a, b = h.grad.view(n, P, 4), href.grad.view(n, P, 4)
+    a, b = h.grad.view(P, n, 4).transpose(0, 1), href.grad.view(P, n, 4).transpose(0, 1)
     scale = b.abs().amax(dim=(1, 2), keepdim=True) + 1e-20   # per sample: the normal gradients span many decades
     assert float(((a - b).abs() / scale).max()) < 2e-3
     assert torch.isfinite(a).all() == torch.isfinite(b).all()

@@ -1,0 +1,39 @@
+"""Development build: the product sources compiled with -DMI3D_DEV into tools/bin/libmi3d_dev.so (git-ignored,
+travels with gpurun).  The extra entry point mi3d_dev_set(index, value) overrides the tunables of csrc/mi3d_dev.h so
+tools/kbench.py can A/B kernel variants and launch geometries in ONE GPU call.  Never loaded by the product: only a
+process that sets MI3D_LIB to this file sees it.
+    python tools/build_dev.py"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "make-it-3d_amd", "csrc")
+OUT_DIR = os.path.join(ROOT, "tools", "bin")
+OUT = os.path.join(OUT_DIR, "libmi3d_dev.so")
+UNITS = [("raymarching.hip", ["-ffp-contract=off"]), ("hashgrid.hip", []), ("field.hip", [])]
+DEV_UNIT = """
+extern "C" int mi3d_dev_tunable[32] = {-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1};
+extern "C" void mi3d_dev_set(int i, int v) { if (i >= 0 && i < 32) mi3d_dev_tunable[i] = v; }
+"""
+
+
+def build():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    objs = []
+    dev_src = os.path.join(OUT_DIR, "dev_tunables.cpp")
+    open(dev_src, "w").write(DEV_UNIT)
+    for name, extra in UNITS + [(dev_src, [])]:
+        src = name if os.path.isabs(name) else os.path.join(CSRC, name)
+        obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        lang = ["-x", "hip"] if src.endswith(".cpp") else []
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMI3D_DEV", *extra, *lang,
+                               "-c", src, "-o", obj])
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build())

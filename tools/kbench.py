@@ -1,0 +1,151 @@
+"""Kernel A/B micro-benchmarks on the C2-dense view (development aid; bench.py is the contract).  Loads the DEV build
+(tools/bin/libmi3d_dev.so, tools/build_dev.py) so kernel variants and launch geometries can be switched at run time:
+    python tools/build_dev.py && python tools/kbench.py [--what encode,levels,mlp,scatter] [--out gpurun_out/kbench.json]
+Every timing is HIP-event time on the launch stream, averaged over `--iters` launches after one warm-up."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "make-it-3d_amd")]
+os.environ.setdefault("MI3D_LIB", os.path.join(ROOT, "tools", "bin", "libmi3d_dev.so"))
+
+import torch  # noqa: E402
+
+T_ENCODE_VARIANT, T_ENCODE_WGS, T_ENCODE_ONLY_LEVEL, T_EMIT_FINE, T_EMIT_COARSE = 0, 1, 2, 3, 4
+T_MLP_WGS, T_REUSE_LEVELS = 7, 10
+
+
+def timeit(fn, iters=3, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="encode,levels,mlp,scatter")
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--bitfield", default="dense")
+    ap.add_argument("--out", default="gpurun_out/kbench.json")
+    a = ap.parse_args()
+    what = set(a.what.split(","))
+    import raymarching
+    from mi3d import _lib as L, field_ops, grid_ops, network, rays as R, sds_step
+    lib = L.lib()
+    lib.mi3d_dev_set.argtypes = [C.c_int, C.c_int]
+
+    def tune(i, v):
+        lib.mi3d_dev_set(i, v)
+    dev = torch.device("cuda:0")
+    cfg = dict(n_levels=16, base_resolution=16, per_level_scale=1.3819128274917603, log2_hashmap_size=19)
+    model = network.NeRFNetwork(sds_step.make_opt()).to(dev)
+    sds_step.set_bitfield(model, a.bitfield if a.bitfield == "dense" else float(a.bitfield))
+    ro, rd, _ = R.view_rays(128, 128, device=dev)
+    ro, rd = ro.view(-1, 3), rd.view(-1, 3)
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, model.aabb_train)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    xs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1.0, model.density_bitfield, 1, 128, nears, fars, cnt,
+                                                          -1, True, 128, True, 0, 1024)
+    xs = xs.contiguous()
+    n = xs.shape[0]
+    xs2 = (xs + torch.randn_like(xs) * 0.01).contiguous()
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    _, offs_p = grid_ops._offs_arg(offs)
+    P = 13
+    params = torch.empty(12196240, device=dev).uniform_(-1, 1)
+    res = {"samples": n, "evals": n * P}
+    feats = torch.empty(16, P * n, 2, device=dev)
+
+    def encode(out=feats):
+        L.call("mi3d_grid_encode_points_planes", L.ptr(xs), L.ptr(xs2), n, offs_p, int(P0), P, 1.0, L.ptr(params), 16, 16,
+               cfg["per_level_scale"], 19, L.ptr(out), L.stream())
+
+    if "encode" in what:
+        tune(T_ENCODE_VARIANT, 0)
+        encode()
+        ref = feats.clone()
+        for v in (0, 1, 2, 3):
+            tune(T_ENCODE_VARIANT, v)
+            feats.zero_()
+            ms = timeit(encode, a.iters)
+            res[f"encode_variant{v}_ms"] = ms
+            res[f"encode_variant{v}_bitexact"] = bool(torch.equal(feats, ref))
+        del ref
+        tune(T_ENCODE_VARIANT, 3)
+        for w in (1, 2, 3, 4):
+            tune(T_ENCODE_WGS, w)
+            res[f"encode_v3_wgs{w}_ms"] = timeit(encode, a.iters)
+        tune(T_ENCODE_WGS, -1)
+        for rl in (0, 4, 6, 8, 10):
+            tune(T_REUSE_LEVELS, rl)
+            res[f"encode_v3_reuse_levels{rl}_ms"] = timeit(encode, a.iters)
+        tune(T_REUSE_LEVELS, -1)
+    if "levels" in what:
+        for v in (0, 3):
+            tune(T_ENCODE_VARIANT, v)
+            per = []
+            for l in range(16):
+                tune(T_ENCODE_ONLY_LEVEL, l)
+                per.append(timeit(encode, 2))
+            res[f"encode_variant{v}_per_level_ms"] = per
+        tune(T_ENCODE_ONLY_LEVEL, -1)
+        tune(T_ENCODE_VARIANT, -1)
+        encode()
+    if "mlp" in what:
+        net = model.sigma_net.net
+        ws = [t.detach().contiguous() for l in net for t in (l.weight, l.bias)]
+        h = torch.empty(P * n, 4, device=dev)
+
+        def fwd(rows=P * n):
+            L.call("mi3d_mlp_forward", L.ptr(feats), P * n, rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1, L.ptr(h),
+                   L.stream())
+        res["mlp_fwd_ms"] = timeit(fwd, a.iters)
+        dh = torch.randn(P * n, 4, device=dev)
+        dplanes = torch.empty(16, P * n, 2, device=dev)
+        grads = [torch.zeros_like(t) for t in ws]
+        absmax = torch.zeros(16, device=dev)
+
+        def bwd(rows=P * n):
+            L.call("mi3d_mlp_backward", L.ptr(feats), P * n, L.ptr(dh), rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1,
+                   L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream())
+        for w in (1, 2, 4):
+            tune(T_MLP_WGS, w)
+            res[f"mlp_bwd_wgs{w}_ms"] = timeit(bwd, a.iters)
+        tune(T_MLP_WGS, -1)
+        res["mlp_bwd_ms"] = timeit(bwd, a.iters)
+        res["mlp_bwd_point0_only_ms"] = timeit(lambda: bwd(n), a.iters)
+        res["mlp_bwd_TFLOPs"] = P * n * 25600.0 / res["mlp_bwd_ms"] / 1e9
+        res["mlp_bwd_stream_TBps"] = P * n * (128 + 16 + 128) / res["mlp_bwd_ms"] / 1e9
+        del dplanes, dh, h
+    if "scatter" in what:
+        step = 2 * 3 ** 0.5 / 1024
+        g = torch.randn(16, P * n, 2, device=dev)
+        absmax = g.abs().amax(dim=(1, 2)).contiguous()
+        for name, am in (("fp32", None), ("half", absmax)):
+            res[f"scatter_{name}_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
+                xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240, level_absmax=am), a.iters)
+        g1 = g[:, :n].contiguous()
+        res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
+            xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
+        for fw in (1024, 4096):
+            tune(T_EMIT_FINE, fw)
+            res[f"scatter_fp32_P13_fine_waves{fw}_ms"] = timeit(lambda: field_ops.scatter_binned(
+                xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
+        tune(T_EMIT_FINE, -1)
+    print(json.dumps(res, indent=1))
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

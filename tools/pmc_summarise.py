@@ -1,30 +1,82 @@
-"""Turns rocprofv3 --pmc counter_collection CSVs into profiles/pmc_r01.json entries.
-    python tools/pmc_summarise.py <kernel-substring> <workload> <evals-per-launch> <FETCH csv> <WRITE csv> [out json]
-FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their bytes
-(/opt/skills/guides/MI355X_MICROARCH.md, HBM section), so fetched bytes are doubled; WRITE_SIZE is taken as reported."""
-import csv, json, os, sys
+"""rocprofv3 --pmc counter_collection CSVs -> profiles/pmc_rNN.json.
+    python tools/pmc_summarise.py <out json> <workload> <evals per full launch> <csv> [<csv> ...]
+Every CSV is one --pmc pass of tools/field_bench.py (FETCH_SIZE and WRITE_SIZE need a pass each: TCC slots).  For each
+kernel family the per-launch averages of every counter are recorded, plus
+  hbm_bytes_per_eval = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / evals   (gfx950: FETCH_SIZE counts wide reads at half
+                       their bytes, /opt/skills/guides/MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported)
+  mfma_busy_frac     = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)
+  lds_conflict_frac  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+Only the LARGEST launches of a family (>= half of its maximum grid-independent duration proxy: the counter itself)
+would skew nothing here: the two backward passes differ 13x in size, so families are split by launch size into
+'full' (all 13 points) and 'point0'."""
+import csv
+import json
+import os
+import sys
+
+FAMILIES = {
+    "k_grid_encode_planes": "k_grid_encode_planes", "k_mlp_forward": "k_mlp_forward", "k_mlp_backward": "k_mlp_backward",
+    "k_bin_emit16": "k_bin_emit16", "k_bin_emit": "k_bin_emit(", "k_bin_reduce": "k_bin_reduce",
+    "k_head_forward": "k_head_forward", "k_head_backward": "k_head_backward", "k_march_train": "k_march_train",
+    "k_composite_train_fwd": "k_composite_train_fwd", "k_composite_train_bwd": "k_composite_train_bwd",
+}
 
 
-def per_launch(path, sub, counter):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if sub in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    return sum(vals) / len(vals), len(vals)
+def family(kernel_name):
+    for fam, sub in FAMILIES.items():
+        if sub in kernel_name or (fam == "k_bin_emit" and "k_bin_emit" in kernel_name and "emit16" not in kernel_name):
+            return fam
+    return None
 
 
 def main():
-    sub, workload, evals, fcsv, wcsv = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5]
-    out = sys.argv[6] if len(sys.argv) > 6 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             "profiles", "pmc_r01.json")
-    f_kb, nf = per_launch(fcsv, sub, "FETCH_SIZE")
-    w_kb, nw = per_launch(wcsv, sub, "WRITE_SIZE")
-    fetched, written = 2.0 * f_kb * 1024.0, w_kb * 1024.0
-    rec = {"launches_sampled": [nf, nw], "FETCH_SIZE_KB_per_launch_raw": f_kb, "WRITE_SIZE_KB_per_launch_raw": w_kb,
-           "fetch_bytes_per_launch_corrected_x2": fetched, "write_bytes_per_launch": written,
-           "evals_per_launch": evals, "hbm_bytes_per_eval": (fetched + written) / evals}
+    out, workload, evals = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    acc = {}
+    for path in sys.argv[4:]:
+        for r in csv.DictReader(open(path)):
+            fam = family(r["Kernel_Name"])
+            if fam is None:
+                continue
+            key = (fam, r["Counter_Name"])
+            acc.setdefault(key, []).append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
     db = json.load(open(out)) if os.path.exists(out) else {}
-    db.setdefault(sub, {})[workload] = rec
+    fams = sorted({k[0] for k in acc})
+    for fam in fams:
+        rec = {}
+        for (f, counter), vals in acc.items():
+            if f != fam:
+                continue
+            v = [x for _, x in vals]
+            big = max(v)
+            full = [x for x in v if x >= 0.5 * big] or v
+            small = [x for x in v if x < 0.5 * big]
+            rec[counter] = {"per_launch_full": sum(full) / len(full), "launches_full": len(full)}
+            if small:
+                rec[counter].update({"per_launch_point0": sum(small) / len(small), "launches_point0": len(small)})
+        g = lambda c: rec.get(c, {}).get("per_launch_full")
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            rec["fetch_bytes_per_launch_corrected_x2"] = 2.0 * g("FETCH_SIZE") * 1024.0
+            rec["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+            rec["evals_per_launch"] = evals
+            rec["hbm_bytes_per_eval"] = (rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]) / evals
+        if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("GRBM_GUI_ACTIVE"):
+            rec["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") * 256 * 4)
+        if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+        db.setdefault(fam, {})[workload] = rec
+    # the scatter as bench.py times it: every emit (+ emit16) and reduce launch of one full-size call (all slices);
+    # the number of full-size calls in the trace = the number of full-size MLP backward launches
+    parts = [db[f][workload] for f in ("k_bin_emit", "k_bin_emit16", "k_bin_reduce") if f in db and workload in db[f]]
+    calls = db.get("k_mlp_backward", {}).get(workload, {}).get("FETCH_SIZE", {}).get("launches_full", 0)
+    if parts and calls and all("FETCH_SIZE" in p and "WRITE_SIZE" in p for p in parts):
+        total = sum((2.0 * p["FETCH_SIZE"]["per_launch_full"] * p["FETCH_SIZE"]["launches_full"] +
+                     p["WRITE_SIZE"]["per_launch_full"] * p["WRITE_SIZE"]["launches_full"]) * 1024.0 for p in parts)
+        db.setdefault("scatter_binned", {})[workload] = {
+            "hbm_bytes_per_eval": total / calls / evals, "calls": calls,
+            "note": "emit (+ emit16) + reduce launches of one full-size scatter call (all slices), FETCH x2 + WRITE"}
     json.dump(db, open(out, "w"), indent=1)
-    print(json.dumps(rec, indent=1))
+    print(json.dumps({f: {k: v for k, v in db[f][workload].items() if not isinstance(v, dict)} for f in db
+                      if workload in db[f]}, indent=1))
 
 
 if __name__ == "__main__":
