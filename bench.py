@@ -95,7 +95,9 @@ def cpu_baseline_reference(wl, budget_s=20.0):
     from mi3d import rays as R
     from oracle import ref_import
     ref_import.install()
-    cores = os.cpu_count() or 1
+    # threads actually used: torch's intra-op pool; beyond a few dozen threads these small gather / index_add ops slow
+    # down (measured on the 256-core GPU box), so the pool is capped and `cores` reports the cap
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     opt = ref_import.default_opt(cuda_ray=False, lambda_smooth=1.0, max_steps=wl["max_steps"])
     torch.manual_seed(0)
@@ -168,14 +170,27 @@ def cpu_baseline_port(wl, budget_s=20.0):
                       f"{dt:.1f} s, extrapolated to the full view"}
 
 
-def cpu_baseline(wl):
-    try:
-        from oracle import ref_import
-        if ref_import.available():
-            return cpu_baseline_reference(wl)
-    except Exception as e:  # fall through to the port, but say why
-        sys.stderr.write(f"[bench] reference CPU baseline unavailable: {e!r}\n")
-    return cpu_baseline_port(wl)
+def log(msg):
+    sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {msg}\n")
+    sys.stderr.flush()
+
+
+def cpu_baseline(workload, hard_limit_s=150):
+    """Runs in a child process with a hard wall-clock limit (the leg must never hold the bench line hostage): the
+    reference's PyTorch renderer when the staged sources exist, else - or on timeout / failure - the C port."""
+    for kind in ("reference", "port"):
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload",
+                                  workload], capture_output=True, text=True, timeout=hard_limit_s)
+            for ln in reversed(out.stdout.strip().splitlines()):
+                if ln.startswith("{"):
+                    return json.loads(ln)
+            log(f"cpu baseline ({kind}) printed no result: {out.stderr[-300:]}")
+        except subprocess.TimeoutExpired:
+            log(f"cpu baseline ({kind}) exceeded {hard_limit_s} s")
+        except Exception as e:
+            log(f"cpu baseline ({kind}) failed: {e!r}")
+    return {"value": None, "error": "both CPU baseline legs failed"}
 
 
 def spawn_ranks(n):
@@ -197,7 +212,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-shaped", action="store_true")
     ap.add_argument("--init-scale", type=float, default=0.25, help="GradScaler initial loss scale")
+    ap.add_argument("--cpu-baseline-only", default=None, choices=["reference", "port"], help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:   # child process of cpu_baseline(): host cores only, no GPU
+        wl = WORKLOADS[args.workload]
+        if args.cpu_baseline_only == "reference":
+            from oracle import ref_import
+            if not ref_import.available():
+                raise SystemExit("reference sources not staged")
+            print(json.dumps(cpu_baseline_reference(wl)))
+        else:
+            print(json.dumps(cpu_baseline_port(wl)))
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)
@@ -299,7 +326,9 @@ def main():
                              f"update (GradScaler overflow, scale now {scaler.get_scale()})")
         return elapsed, prof
 
+    log(f"{args.workload}: timing {args.steps} steps of the headline variant {HEADLINE} on {world} GPU(s)")
     elapsed, prof = run(*HEADLINE, args.steps, args.warmup)
+    log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step")
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
     if args.variant_steps > 0 and not render_only:
         for rec in ("fp32", "half"):
@@ -374,6 +403,7 @@ def main():
     # ---- baselines (rank 0 of a single-GPU run only; never part of the timed region above)
     if rank == 0 and world == 1:
         if not args.no_reference_shaped and not render_only:
+            log("reference-shaped baseline (reference Python on the drop-in packages)")
             try:
                 line["reference_shaped_baseline"] = reference_shaped(model, guidance, text_z, opt, view_rays[0], wl,
                                                                      t_fixed, dev, args.init_scale)
@@ -382,10 +412,9 @@ def main():
             if line["reference_shaped_baseline"].get("value"):
                 line["speedup_vs_reference_shaped"] = line["value"] / line["reference_shaped_baseline"]["value"]
         if not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(wl)
-            except Exception as e:  # the baseline leg must never take the bench line down with it
-                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+            log("cpu baseline (child process, hard limit 150 s per leg)")
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        log("done")
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -411,8 +440,12 @@ def reference_shaped(model, guidance, text_z, opt, rays, wl, t_fixed, dev, init_
     def step():
         sds_step.sds_train_step(ref_model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
                                 sds_backward="reference", t=t_fixed)
+    t0 = time.perf_counter()
     step()
     torch.cuda.synchronize()
+    first = time.perf_counter() - t0
+    log(f"reference-shaped warm-up step: {first:.2f} s")
+    steps = 1 if first > 15 else steps   # bounded: the leg must not stretch the default run
     t0 = time.perf_counter()
     for _ in range(steps):
         step()

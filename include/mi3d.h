@@ -134,10 +134,11 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
                             uint32_t log2_hashmap_size, float *out, void *stream);
 /* mi3d_grid_encode_points with level-major output planes [n_levels][P*n][2] (feature pair of level l, row r = p*n + i
  * at out_planes[(l*P*n + r)*2]) - the layout the MLP kernels take with x_plane_rows = P*n.  The (level, tile) work is
- * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from. */
+ * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from; `step` (the marching
+ * step in world units, 0 = unknown) only balances that split, never the result. */
 int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
-                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                                    float *out_planes, void *stream);
 int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
                              const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,

@@ -362,8 +362,10 @@ struct Grads {
     float *dW1, *db1, *dW2, *db2, *dW3, *db3;
 };
 
-template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
+// WPS = waves per SIMD the register allocation is held to (1: up to 512 registers, 2: 256 with the overflow spilled),
+// PREFETCH = request the next tile's rows before computing the current one.
+template <class P, int WPS, bool PREFETCH>
+__global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
                                                                       const float *__restrict__ dout, uint32_t n,
                                                                       Weights w, float *__restrict__ dx,
                                                                       uint32_t dx_planes,
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
     // iteration later (round 1 waited ~6.7 us per tile for its own rows, 5 % of the matrix peak).
     float raw[16];
     f32x4 dor = {0.f, 0.f, 0.f, 0.f};
-    if (wave < n_tiles) {
+    if (PREFETCH && wave < n_tiles) {
         const size_t r0 = (size_t)wave * 32 + p;
         load_rows_raw(x, r0, n, h, x_planes, raw);
         dor = load_dout_raw(dout, r0, n);
@@ -410,9 +412,13 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_backward(const float
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row0 = (size_t)tile * 32, row = row0 + p;
         const bool valid = row < n;
+        if (!PREFETCH) {
+            load_rows_raw(x, row, n, h, x_planes, raw);
+            dor = load_dout_raw(dout, row, n);
+        }
         const typename P::KB X = rows_kb<P>(raw);
         const typename P::KB dO = dout_kb<P>(dor, valid && h == 0);
-        if (tile + n_waves < n_tiles) {
+        if (PREFETCH && tile + n_waves < n_tiles) {
             const size_t rn = (size_t)(tile + n_waves) * 32 + p;
             load_rows_raw(x, rn, n, h, x_planes, raw);
             dor = load_dout_raw(dout, rn, n);
@@ -763,12 +769,32 @@ int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, 
     if (n == 0) return 0;
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
+    const dim3 grid(grid_for(n)), block(kWave * kWavesPerWG);
+    hipStream_t st = as_stream(stream);
+#ifdef MI3D_DEV
+    const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
+    if (half_mode && variant == 1) {
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+                           n, w, dx, dx_plane_rows, level_absmax, g);
+        return (int)hipGetLastError();
+    }
+    if (half_mode && variant == 2) {
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+                           n, w, dx, dx_plane_rows, level_absmax, g);
+        return (int)hipGetLastError();
+    }
+    if (half_mode && variant == 3) {
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+                           n, w, dx, dx_plane_rows, level_absmax, g);
+        return (int)hipGetLastError();
+    }
+#endif
     if (half_mode)
-        hipLaunchKernelGGL(k_mlp_backward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_ALL_COUNT), as_stream(stream), x, x_plane_rows, dout, n, w, dx, dx_plane_rows, level_absmax, g);
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+                           n, w, dx, dx_plane_rows, level_absmax, g);
     else
-        hipLaunchKernelGGL(k_mlp_backward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_ALL_COUNT), as_stream(stream), x, x_plane_rows, dout, n, w, dx, dx_plane_rows, level_absmax, g);
+        hipLaunchKernelGGL((k_mlp_backward<F32, 1, true>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+                           n, w, dx, dx_plane_rows, level_absmax, g);
     return (int)hipGetLastError();
 }
 

@@ -121,16 +121,19 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 // Output is level-major planes [L][P*n][2], row = p*n + s (point-major): the 64 lanes of a wave store 512 contiguous
 // bytes per point, and the MLP kernels read them with x_plane_rows = P*n.
 //
-// The gather itself is bound by the L1's line-lookup rate (one distinct line per clock per CU; round 1 measured 18.1 G
-// lane-addresses in 40 ms), so the kernel spends lookups sparingly:
+// What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level): levels 0-7 cost 1.3-1.5 ms each,
+// then the cost climbs with the number of distinct lines a wave's 64 consecutive samples touch - 1.7 / 2.1 / 2.6 / 3.2 /
+// 3.8 ms for levels 8-12 - and saturates at 4.06 ms for levels 13-15, where every lane is in its own line:
+// 141 M evaluations x 8 corners x one 128-byte line from the L2 = 145 GB per level against the L2s' ~34.5 TB/s
+// (MI355X_MICROARCH.md) = 4.2 ms.  The gather is L2->L1 line-bandwidth bound (16x the bytes it uses), the sum over the
+// levels is 36 ms when the XCDs are evenly loaded - which the segments below are for - and the only bytes that can be
+// saved are the second lookup of a line:
 //   PAIR   the x and x+1 corners of a (y, z) corner pair are neighbours in memory whenever their entry indices differ
 //          in bit 0 only - every even cx on hashed levels (x enters the hash with prime 1), every even entry index on
 //          dense ones: one 16-byte load of the aligned slot serves both, the x+1 corner is fetched separately only
-//          where the pair straddles a slot.
-//   REUSE  on levels whose cells are longer than the finite-difference epsilon the six neighbours of a sample mostly
-//          sit in the sample's own cell: the 8 corner values of the sample's cell (and of the last other cell
-//          touched) stay in registers and a stencil point that lands in either re-uses them.  Same values, same
-//          summation order: bit-identical features.
+//          where the pair straddles a slot (measured: -10 % on the saturated levels).
+// (Keeping the corner values of the sample's own cell in registers for its +-eps neighbours was measured too: the
+// coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower.)
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
 
@@ -138,12 +141,6 @@ struct EncodeSeg { uint32_t level, tile0, tile1; };
 struct EncodePlan {
     uint32_t n_seg[kXcds];
     EncodeSeg seg[kXcds][kMaxSegs];
-    uint32_t reuse_levels;  // levels below this keep two cells of corner values in registers
-};
-
-struct CellVals {
-    uint32_t cx, cy, cz;
-    float2 v[8];
 };
 
 template <bool PAIR>
@@ -174,7 +171,7 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
     }
 }
 
-template <bool PAIR, bool REUSE>
+template <bool PAIR>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
                                                                        EncodePlan plan, float2 *__restrict__ planes) {
@@ -188,14 +185,11 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
         float2 *plane = planes + (size_t)l * rows_total;
-        const bool reuse = REUSE && l < plan.reuse_levels;
         for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
             const uint32_t s = tile * kTile + lane;
-            const bool valid = s < n;
+            if (s >= n) continue;
             float base[2][3];
-            load_bases(ps, s, valid, base);
-            CellVals A, B;  // A: the cell of point 0, B: the last other cell gathered
-            A.cx = A.cy = A.cz = B.cx = B.cy = B.cz = 0xFFFFFFFFu;
+            load_bases(ps, s, true, base);
             for (uint32_t p = 0; p < ps.P; ++p) {
                 float q[3];
                 point_of(ps, base, p, q);
@@ -205,63 +199,42 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                 grid_cell(q[1], L.scale, cy, fy);
                 grid_cell(q[2], L.scale, cz, fz);
                 float2 v[8];
-                bool need = valid;
-                if (REUSE && reuse) {
-                    const bool hitA = cx == A.cx && cy == A.cy && cz == A.cz;
-                    const bool hitB = cx == B.cx && cy == B.cy && cz == B.cz;
+                gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
+                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
+                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+                const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+                float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = hitA ? A.v[k] : B.v[k];
-                    need = valid && !(hitA || hitB);
-                }
-                if (need) {
-                    gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
-                    if (REUSE && reuse) {
-                        if (p == 0) {
-                            A.cx = cx; A.cy = cy; A.cz = cz;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) A.v[k] = v[k];
-                        } else {
-                            B.cx = cx; B.cy = cy; B.cz = cz;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) B.v[k] = v[k];
-                        }
-                    }
-                }
-                if (valid) {
-                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                    // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
-                    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
-                    const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                    float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
-                    plane[(size_t)p * n + s] = make_float2(r0, r1);
-                }
+                for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
+                plane[(size_t)p * n + s] = make_float2(r0, r1);
             }
         }
     }
 }
 
-// The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.  A level's cost per tile is the
-// share of its stencil points that still gather once cell reuse is on: a +-eps neighbour leaves its centre's cell with
-// probability ~ eps * scale (capped at 1); the centre points always gather.
-inline EncodePlan make_encode_plan(const GridTable &T, const PointSet &ps, uint32_t n_tiles, bool reuse, int only_level) {
+// Relative cost of one tile of a level, as a function of x = (marching step) x (level scale) = how many cells of the
+// level two consecutive samples of a ray are apart: the measured per-level times above, tabulated against x (C2: step
+// 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
+inline double encode_level_cost(double x) {
+    static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
+    static const double cs[] = {1.30, 1.32, 1.40, 1.51, 1.66, 1.95, 2.45, 3.15, 3.55, 3.65, 3.67, 3.67};
+    constexpr int N = sizeof(xs) / sizeof(xs[0]);
+    if (x <= xs[0]) return cs[0];
+    for (int i = 1; i < N; ++i)
+        if (x < xs[i]) return cs[i - 1] + (cs[i] - cs[i - 1]) * (x - xs[i - 1]) / (xs[i] - xs[i - 1]);
+    return cs[N - 1];
+}
+
+// The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
+inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level) {
     EncodePlan plan{};
-    double span = 0.0;  // largest stencil offset in [0,1] units
-    for (uint32_t i = 0; i < ps.P * 3; ++i) span = fmax(span, fabs((double)ps.offs[i]));
-    span = ps.mode == 0 ? 0.0 : span / (2.0 * (double)ps.bound);
-    const uint32_t groups = ps.P0 < ps.P ? 2u : 1u;
     double cost[MI3D_MAX_LEVELS], total = 0.0;
-    uint32_t reuse_levels = 0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
-        double hit = reuse && ps.P > 1 && span > 0.0 ? 1.0 - span * (double)T.level[l].scale : 0.0;
-        hit = hit < 0.0 ? 0.0 : hit;
-        if (hit > 0.15) reuse_levels = l + 1; else hit = 0.0;
-        cost[l] = 1.0 - hit * (double)(ps.P - groups) / (double)ps.P;
+        cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale);
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
         total += cost[l];
     }
-    plan.reuse_levels = reuse_levels;
     const double share = total / kXcds;
     uint32_t x = 0;
     double filled = 0.0;  // cost already given to XCD x
@@ -1133,7 +1106,7 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
 
 int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
-                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                                   uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                                    float *out_planes, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
         (P0 < P && x2 == nullptr))
@@ -1143,23 +1116,20 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const uint32_t tiles = (n + kTile - 1) / kTile;
-    const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 3);
-    const bool pair = variant & 1, reuse = (variant & 2) && P > 1;
-    EncodePlan plan = make_encode_plan(T, ps, tiles, reuse, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
-    const int rl = MI3D_TUNE(MI3D_T_ENCODE_REUSE_LEVELS, -1);
-    if (rl >= 0) plan.reuse_levels = (uint32_t)rl;
+    const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
+    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
     uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
-    const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 2);  // round 1: 2 -> 39.9 ms, 4 -> 43.0 ms at C2
+    const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
     const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU
     per_xcd = per_xcd < cap ? per_xcd : cap;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     const float2 *tab = reinterpret_cast<const float2 *>(params);
     float2 *out = reinterpret_cast<float2 *>(out_planes);
     hipStream_t st = as_stream(stream);
-    if (pair && reuse) hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out);
-    else if (pair) hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out);
-    else if (reuse) hipLaunchKernelGGL((k_grid_encode_planes<false, true>), grid, block, 0, st, ps, n, tab, T, plan, out);
-    else hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out);
+    if (MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 1) & 1)
+        hipLaunchKernelGGL((k_grid_encode_planes<true>), grid, block, 0, st, ps, n, tab, T, plan, out);
+    else
+        hipLaunchKernelGGL((k_grid_encode_planes<false>), grid, block, 0, st, ps, n, tab, T, plan, out);
     return (int)hipGetLastError();
 }
 

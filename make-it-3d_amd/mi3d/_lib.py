@@ -38,7 +38,7 @@ _SIGNATURES = {
     # Part 3 ------------------------------------------------------------------------------------------
     "mi3d_grid_encode_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, vp, vp],
     "mi3d_grid_scatter_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
-    "mi3d_grid_encode_points_planes": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, vp, vp],
+    "mi3d_grid_encode_points_planes": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
     "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp, C.c_size_t, vp, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],

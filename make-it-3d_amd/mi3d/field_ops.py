@@ -66,21 +66,21 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     return grad
 
 
-# When True (the default) the fine levels of the scatter use 8-byte {entry, binary16 pair} records under
-# torch.autocast(float16) - the upstream feature gradient is binary16 there anyway, but every corner contribution
-# w * dfeature is then ROUNDED to binary16 where tiny-cuda-nn adds the fp32 product (gradients within ~1e-3 of the fp32
-# path instead of ~1e-5).  False keeps 12-byte fp32 records on every level: the like-for-like arithmetic.
+# False (the default): 12-byte fp32 gradient records on every level - the like-for-like arithmetic (tiny-cuda-nn adds
+# fp32 products).  True: under torch.autocast(float16) the fine levels use 8-byte {entry, binary16 pair} records - the
+# upstream feature gradient is binary16 there anyway, but every corner contribution w * dfeature is then ROUNDED to
+# binary16 (gradients within ~1e-3 of the fp32 path instead of ~1e-5); an opt-in that bench.py reports as a variant.
 HALF_RECORDS = False
 
 
-def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode):
+def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step=0.0):
     """feats [L][P*n][2] and h [P*n, 4] (point-major rows)."""
     P, n = offs.shape[0], x.shape[0]
     feats = torch.empty(cfg["n_levels"], P * n, 2, dtype=torch.float32, device=x.device)
     grid_ops._timed("encode", lambda: L.call(
         "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
-        cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], L.ptr(feats),
-        L.stream(x)), n * P)
+        cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
+        L.ptr(feats), L.stream(x)), n * P)
     dims = (ws[0].shape[1], ws[0].shape[0], ws[4].shape[0])
     h = torch.empty(P * n, dims[2], dtype=torch.float32, device=x.device)
     grid_ops._timed("mlp_fwd", lambda: L.call(
@@ -121,7 +121,7 @@ class _FieldStencil(Function):
         ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
         offs, offs_p = grid_ops._offs_arg(offsets)
         with L.on(x):
-            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode)
+            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step)
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, *ws)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
                     int(half_mode))
@@ -253,7 +253,7 @@ class _Field(Function):
         if offs.shape[0] not in (7, 13):
             raise L.Mi3dError("the fused field takes the 7- or 13-point stencil")
         with L.on(x):
-            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode)
+            feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step)
             sigma, albedo, normal, normal2 = _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius,
                                                            epsilon)
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, h, *ws)

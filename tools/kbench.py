@@ -68,30 +68,26 @@ def main():
 
     def encode(out=feats):
         L.call("mi3d_grid_encode_points_planes", L.ptr(xs), L.ptr(xs2), n, offs_p, int(P0), P, 1.0, L.ptr(params), 16, 16,
-               cfg["per_level_scale"], 19, L.ptr(out), L.stream())
+               cfg["per_level_scale"], 19, 2 * 3 ** 0.5 / 1024, L.ptr(out), L.stream())
 
     if "encode" in what:
         tune(T_ENCODE_VARIANT, 0)
         encode()
         ref = feats.clone()
-        for v in (0, 1, 2, 3):
+        for v in (0, 1):
             tune(T_ENCODE_VARIANT, v)
             feats.zero_()
             ms = timeit(encode, a.iters)
             res[f"encode_variant{v}_ms"] = ms
             res[f"encode_variant{v}_bitexact"] = bool(torch.equal(feats, ref))
         del ref
-        tune(T_ENCODE_VARIANT, 3)
-        for w in (1, 2, 3, 4):
+        tune(T_ENCODE_VARIANT, 1)
+        for w in (2, 3, 4, 6):
             tune(T_ENCODE_WGS, w)
-            res[f"encode_v3_wgs{w}_ms"] = timeit(encode, a.iters)
+            res[f"encode_v1_wgs{w}_ms"] = timeit(encode, a.iters)
         tune(T_ENCODE_WGS, -1)
-        for rl in (0, 4, 6, 8, 10):
-            tune(T_REUSE_LEVELS, rl)
-            res[f"encode_v3_reuse_levels{rl}_ms"] = timeit(encode, a.iters)
-        tune(T_REUSE_LEVELS, -1)
     if "levels" in what:
-        for v in (0, 3):
+        for v in (0, 1):
             tune(T_ENCODE_VARIANT, v)
             per = []
             for l in range(16):
@@ -118,9 +114,12 @@ def main():
         def bwd(rows=P * n):
             L.call("mi3d_mlp_backward", L.ptr(feats), P * n, L.ptr(dh), rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1,
                    L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream())
-        for w in (1, 2, 4):
-            tune(T_MLP_WGS, w)
-            res[f"mlp_bwd_wgs{w}_ms"] = timeit(bwd, a.iters)
+        for v in (0, 1, 2, 3):   # 0: 1 wave/SIMD + prefetch, 1: 2 waves/SIMD + prefetch, 2: 2 waves no prefetch, 3: 1 wave no prefetch
+            tune(6, v)
+            for w in ((2, 4) if v in (1, 2) else (2,)):
+                tune(T_MLP_WGS, w)
+                res[f"mlp_bwd_variant{v}_wgs{w}_ms"] = timeit(bwd, a.iters)
+        tune(6, -1)
         tune(T_MLP_WGS, -1)
         res["mlp_bwd_ms"] = timeit(bwd, a.iters)
         res["mlp_bwd_point0_only_ms"] = timeit(lambda: bwd(n), a.iters)
