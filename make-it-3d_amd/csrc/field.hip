@@ -57,6 +57,12 @@ struct F16 {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[0], b.v[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[1], b.v[1], acc, 0, 0, 0);
     }
+    // one K-block product = kSteps matrix instructions; issuing step s of several products before step s + 1 of any
+    // keeps consecutive MFMAs on different accumulators
+    static constexpr int kSteps = 2;
+    __device__ static __forceinline__ void mma_step(f32x16 &acc, const KB &a, const KB &b, int s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[s], b.v[s], acc, 0, 0, 0);
+    }
     // only values q < 8 of both operands are non-zero
     __device__ static __forceinline__ void mma_lo(f32x16 &acc, const KB &a, const KB &b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[0], b.v[0], acc, 0, 0, 0);
@@ -130,6 +136,10 @@ struct F32 {
     __device__ static __forceinline__ void mma(f32x16 &acc, const KB &a, const KB &b) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q], b.v[q], acc, 0, 0, 0);
+    }
+    static constexpr int kSteps = 16;
+    __device__ static __forceinline__ void mma_step(f32x16 &acc, const KB &a, const KB &b, int s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
     }
     __device__ static __forceinline__ void mma_lo(f32x16 &acc, const KB &a, const KB &b) {
 #pragma unroll
@@ -362,14 +372,21 @@ struct Grads {
     float *dW1, *db1, *dW2, *db2, *dW3, *db3;
 };
 
-// WPS = waves per SIMD the register allocation is held to (1: up to 512 registers, 2: 256 with the overflow spilled),
-// PREFETCH = request the next tile's rows before computing the current one.
-template <class P, int WPS, bool PREFETCH>
+// U = tiles (of 32 rows) a wave works on at once, WPS = waves per SIMD the register allocation is held to.
+//
+// One wave per SIMD (the weight-gradient tiles alone are 128 registers), so nothing hides a latency but the wave's own
+// independent work.  Round 2 measured where the time went (tools/kbench.py): prefetching the next tile's rows gained
+// 1 ms of 20, the other 18 are the dependency chain product -> convert / mask -> next product, ~250 cycles per product
+// against 64 on the matrix pipe.  So the kernel is written in STAGES over U = 2 tiles x NTH = 2 output tiles: every
+// stage first issues the matrix products of all its (tile, output-tile) pairs step by step - consecutive MFMAs go to
+// different accumulators - and only then converts them, which gives the in-order wave four independent chains to
+// overlap (the packed converts of one accumulator run under the MFMAs of the next).
+template <class P, int U, int WPS>
 __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
-                                                                      const float *__restrict__ dout, uint32_t n,
-                                                                      Weights w, float *__restrict__ dx,
-                                                                      uint32_t dx_planes,
-                                                                      float *__restrict__ level_absmax, Grads g) {
+                                                                           const float *__restrict__ dout, uint32_t n,
+                                                                           Weights w, float *__restrict__ dx,
+                                                                           uint32_t dx_planes,
+                                                                           float *__restrict__ level_absmax, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_ALL_COUNT);
@@ -377,6 +394,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
     const int lane = threadIdx.x & (kWave - 1), p = lane & 31, h = lane >> 5;
     const uint32_t wave = blockIdx.x * kWavesPerWG + threadIdx.x / kWave, n_waves = gridDim.x * kWavesPerWG;
     const uint32_t n_tiles = (n + 31) / 32;
+    using KB = typename P::KB;
     // the lane offset is laundered through an empty asm so every use is a fresh LDS read: hipcc would otherwise
     // hoist all (loop-invariant) operand blocks into registers and spill the accumulators
     auto blk = [&](int b) {
@@ -399,139 +417,299 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) lvmax[j] = 0.f;
 
-    // One wave per SIMD (the weight-gradient tiles alone are 128 registers), so nothing hides a load but the wave's own
-    // work: the rows of the NEXT tile are requested before the current tile's products start and are consumed one
-    // iteration later (round 1 waited ~6.7 us per tile for its own rows, 5 % of the matrix peak).
-    float raw[16];
-    f32x4 dor = {0.f, 0.f, 0.f, 0.f};
-    if (PREFETCH && wave < n_tiles) {
-        const size_t r0 = (size_t)wave * 32 + p;
-        load_rows_raw(x, r0, n, h, x_planes, raw);
-        dor = load_dout_raw(dout, r0, n);
+    // the rows of the NEXT group of tiles are requested before the current group's products start and are consumed one
+    // iteration later; tile u of a group is `u * n_waves` tiles further on, so every wave instruction still reads 32
+    // consecutive rows
+    float raw[U][16];
+    f32x4 dor[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t r0 = ((size_t)wave + (size_t)u * n_waves) * 32 + p;
+        load_rows_raw(x, r0, n, h, x_planes, raw[u]);
+        dor[u] = load_dout_raw(dout, r0, n);
     }
-    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-        const size_t row0 = (size_t)tile * 32, row = row0 + p;
-        const bool valid = row < n;
-        if (!PREFETCH) {
-            load_rows_raw(x, row, n, h, x_planes, raw);
-            dor = load_dout_raw(dout, row, n);
+    for (uint32_t tile = wave; tile < n_tiles; tile += U * n_waves) {
+        size_t row[U];
+        bool valid[U];
+        KB X[U], dO[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            row[u] = ((size_t)tile + (size_t)u * n_waves) * 32 + p;
+            valid[u] = row[u] < n;
+            X[u] = rows_kb<P>(raw[u]);
+            dO[u] = dout_kb<P>(dor[u], valid[u] && h == 0);
         }
-        const typename P::KB X = rows_kb<P>(raw);
-        const typename P::KB dO = dout_kb<P>(dor, valid && h == 0);
-        if (PREFETCH && tile + n_waves < n_tiles) {
-            const size_t rn = (size_t)(tile + n_waves) * 32 + p;
-            load_rows_raw(x, rn, n, h, x_planes, raw);
-            dor = load_dout_raw(dout, rn, n);
+        if (tile + U * n_waves < n_tiles) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t rn = ((size_t)tile + (size_t)(U + u) * n_waves) * 32 + p;
+                load_rows_raw(x, rn, n, h, x_planes, raw[u]);
+                dor[u] = load_dout_raw(dout, rn, n);
+            }
         }
 
         // ---- orientation 1 (lane = sample): recompute the activations (they double as their own ReLU masks)
-        typename P::KB H1[NTH], H2[NTH];
+        KB H1[U][NTH], H2[U][NTH], dH2[U][NTH], dH1[U][NTH];
+        {
+            f32x16 acc[U][NTH];
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = bias_rows(bias + 32 * t, h);
-            P::mma(acc, blk(B_W1 + t), X);
-            H1[t] = P::relu(acc);
-        }
+            for (int t = 0; t < NTH; ++t)
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = bias_rows(bias + HID + 32 * t, h);
+                for (int u = 0; u < U; ++u) acc[u][t] = bias_rows(bias + 32 * t, h);
+            {
+                KB Wb[NTH];
 #pragma unroll
-            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2 + t * NTH + tk), H1[tk]);
-            H2[t] = P::relu(acc);
-        }
-        // ---- orientation 1: input-side gradients  dH2 = W3^T dO, dH1 = W2^T dH2, dX = W1^T dH1
-        typename P::KB dH2[NTH], dH1[NTH];
+                for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W1 + t);
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = splat(0.f);
-            P::mma_lo(acc, blk(B_W3T + t), dO);
-            dH2[t] = P::masked(acc, H2[t]);
-        }
+                for (int st = 0; st < P::kSteps; ++st)
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = splat(0.f);
+                    for (int t = 0; t < NTH; ++t)
 #pragma unroll
-            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W2T + t * NTH + tk), dH2[tk]);
-            dH1[t] = P::masked(acc, H1[t]);
+                        for (int u = 0; u < U; ++u) P::mma_step(acc[u][t], Wb[t], X[u], st);
+            }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) H1[u][t] = P::relu(acc[u][t]);
         }
         {
-            f32x16 acc = splat(0.f);
+            f32x16 acc[U][NTH];
 #pragma unroll
-            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B_W1T + tk), dH1[tk]);
-            if (valid && !dx_planes) {  // register q = input feature rowmap(q, h): four runs of four features
-                float *dst = dx + row * DIN + 4 * h;
+            for (int t = 0; t < NTH; ++t)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 o = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
-                }
-            } else if (valid) {
-                // level-major planes [DIN/2][dx_planes][2] (what the binned scatter reads): features (2l, 2l+1) of this
-                // row are one 8-byte store; lane-half h owns levels 4c + 2h and 4c + 2h + 1, 32 consecutive rows per store
+                for (int u = 0; u < U; ++u) acc[u][t] = bias_rows(bias + HID + 32 * t, h);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x2 a = {acc[4 * c], acc[4 * c + 1]}, b = {acc[4 * c + 2], acc[4 * c + 3]};
-                    lvmax[2 * c] = absmax_or_inf(lvmax[2 * c], a[0], a[1]);
-                    lvmax[2 * c + 1] = absmax_or_inf(lvmax[2 * c + 1], b[0], b[1]);
-                    const size_t lvl = 4 * c + 2 * h;
-                    __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * dx_planes + row) * 2));
-                    __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * dx_planes + row) * 2));
+            for (int tk = 0; tk < NTH; ++tk) {
+                KB Wb[NTH];
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W2 + t * NTH + tk);
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) P::mma_step(acc[u][t], Wb[t], H1[u][tk], st);
+            }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) H2[u][t] = P::relu(acc[u][t]);
+        }
+        // ---- orientation 1: input-side gradients  dH2 = W3^T dO, dH1 = W2^T dH2, dX = W1^T dH1
+        {
+            f32x16 acc[U][NTH];
+            KB Wb[NTH];
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W3T + t);
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) { acc[u][t] = splat(0.f); P::mma_lo(acc[u][t], Wb[t], dO[u]); }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) dH2[u][t] = P::masked(acc[u][t], H2[u][t]);
+        }
+        {
+            f32x16 acc[U][NTH];
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) {
+                KB Wb[NTH];
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W2T + t * NTH + tk);
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) P::mma_step(acc[u][t], Wb[t], dH2[u][tk], st);
+            }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) dH1[u][t] = P::masked(acc[u][t], H1[u][t]);
+        }
+        {
+            f32x16 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) {
+                const KB Wb = blk(B_W1T + tk);
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) P::mma_step(acc[u], Wb, dH1[u][tk], st);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (valid[u] && !dx_planes) {  // register q = input feature rowmap(q, h): four runs of four features
+                    float *dst = dx + row[u] * DIN + 4 * h;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 o = {acc[u][4 * c], acc[u][4 * c + 1], acc[u][4 * c + 2], acc[u][4 * c + 3]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
+                    }
+                } else if (valid[u]) {
+                    // level-major planes [DIN/2][dx_planes][2] (what the binned scatter reads): features (2l, 2l+1) of
+                    // this row are one 8-byte store; lane-half h owns levels 4c + 2h and 4c + 2h + 1, 32 consecutive
+                    // rows per store
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x2 a = {acc[u][4 * c], acc[u][4 * c + 1]}, b = {acc[u][4 * c + 2], acc[u][4 * c + 3]};
+                        lvmax[2 * c] = absmax_or_inf(lvmax[2 * c], a[0], a[1]);
+                        lvmax[2 * c + 1] = absmax_or_inf(lvmax[2 * c + 1], b[0], b[1]);
+                        const size_t lvl = 4 * c + 2 * h;
+                        __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * dx_planes + row[u]) * 2));
+                        __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * dx_planes + row[u]) * 2));
+                    }
                 }
             }
         }
 
-        // ---- orientation 2 (lane = feature, registers = the tile's 32 samples): operands of the weight gradients
-        // hidden-1 activations and their gradient
-        typename P::KB H1p[NTH], dH2p[NTH];
+        // ---- orientation 2 (lane = feature, registers = the tile's 32 samples): operands of the weight gradients.
+        // (Stages are cut so that at most one set of U x NTH accumulators is live next to the 128 gradient registers.)
+        KB H1p[U][NTH];
+        {   // hidden-1 activations
+            f32x16 acc[U][NTH];
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = splat(bias[32 * t + p]);
-            P::mma(acc, X, blk(B_W1 + t));
-            H1p[t] = P::relu(acc);
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = splat(bias[32 * t + p]);
+            KB Wb[NTH];
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W1 + t);
+#pragma unroll
+            for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) P::mma_step(acc[u][t], X[u], Wb[t], st);
+#pragma unroll
+            for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u) H1p[u][t] = P::relu(acc[u][t]);
         }
-        // dO with lane = output index, values = samples (A operand of dW3): dO (lane = sample) times the identity block
-        // hands it back transposed; its sum over samples is db3
-        typename P::KB dOp;
+        KB dH2p[U][NTH];
         {
-            f32x16 acc = splat(0.f);
-            P::mma_lo(acc, dO, blk(B_ID));
-            dOp = P::cast(acc);
-            gb3 += P::sum(dOp);
-        }
-        // hidden-2 pre-activations (for the mask and for dW3), gradient wrt hidden-2
+            KB H2p[U][NTH], dOp[U];
+            {   // hidden-2 activations (the mask, and the operand of dW3)
+                f32x16 acc[U][NTH];
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 acc = splat(bias[HID + 32 * t + p]);
+                for (int t = 0; t < NTH; ++t)
 #pragma unroll
-            for (int tk = 0; tk < NTH; ++tk) P::mma(acc, H1[tk], blk(B_W2 + t * NTH + tk));
-            const typename P::KB H2p = P::relu(acc);
-            P::mma(gW3[t], dOp, H2p);  // dW3[o][f] += sum_s dO[s][o] H2[s][f]
-            f32x16 d = splat(0.f);
-            P::mma_lo(d, dO, blk(B_W3T + t));
-            dH2p[t] = P::masked(d, H2p);
-            gb2[t] += P::sum(dH2p[t]);
+                    for (int u = 0; u < U; ++u) acc[u][t] = splat(bias[HID + 32 * t + p]);
+#pragma unroll
+                for (int tk = 0; tk < NTH; ++tk) {
+                    KB Wb[NTH];
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W2 + t * NTH + tk);
+#pragma unroll
+                    for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                        for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                            for (int u = 0; u < U; ++u) P::mma_step(acc[u][t], H1[u][tk], Wb[t], st);
+                }
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) H2p[u][t] = P::relu(acc[u][t]);
+            }
+            {   // dO with lane = output index, values = samples: dO (lane = sample) times the identity block hands it
+                // back transposed (no gather loads); its sum over the samples is db3
+                const KB Id = blk(B_ID);
+                f32x16 tO[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { tO[u] = splat(0.f); P::mma_lo(tO[u], dO[u], Id); }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { dOp[u] = P::cast(tO[u]); gb3 += P::sum(dOp[u]); }
+            }
+            // dW3[o][f] += sum_s dO[s][o] H2[s][f]
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t) P::mma_step(gW3[t], dOp[u], H2p[u][t], st);
+            {   // gradient wrt hidden-2
+                f32x16 d[U][NTH];
+                KB Wb[NTH];
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W3T + t);
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { d[u][t] = splat(0.f); P::mma_lo(d[u][t], dO[u], Wb[t]); }
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        dH2p[u][t] = P::masked(d[u][t], H2p[u][t]);
+                        gb2[t] += P::sum(dH2p[u][t]);
+                    }
+            }
         }
         // dW2[i][j] += sum_s dH2[s][i] H1[s][j]
 #pragma unroll
-        for (int ti = 0; ti < NTH; ++ti)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int tj = 0; tj < NTH; ++tj) P::mma(gW2[ti][tj], dH2p[ti], H1p[tj]);
-        // the input rows with lane = input feature (X times the identity block), then the gradient wrt hidden-1 in
-        // orientation 2 and dW1[i][j] += sum_s dH1[s][i] X[s][j]
-        typename P::KB Xp;
-        {
-            f32x16 acc = splat(0.f);
-            P::mma(acc, X, blk(B_ID));
-            Xp = P::cast(acc);
-        }
+            for (int st = 0; st < P::kSteps; ++st)
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) {
-            f32x16 d = splat(0.f);
+                for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
-            for (int tk = 0; tk < NTH; ++tk) P::mma(d, dH2[tk], blk(B_W2T + t * NTH + tk));
-            const typename P::KB dH1p = P::masked(d, H1p[t]);
-            gb1[t] += P::sum(dH1p);
-            P::mma(gW1[t], dH1p, Xp);
+                    for (int tj = 0; tj < NTH; ++tj) P::mma_step(gW2[ti][tj], dH2p[u][ti], H1p[u][tj], st);
+        {   // the gradient wrt hidden-1 in orientation 2, the input rows with lane = input feature (X times the
+            // identity block), and dW1[i][j] += sum_s dH1[s][i] X[s][j]
+            KB dH1p[U][NTH], Xp[U];
+            {
+                f32x16 d[U][NTH];
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) d[u][t] = splat(0.f);
+#pragma unroll
+                for (int tk = 0; tk < NTH; ++tk) {
+                    KB Wb[NTH];
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t) Wb[t] = blk(B_W2T + t * NTH + tk);
+#pragma unroll
+                    for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                        for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                            for (int u = 0; u < U; ++u) P::mma_step(d[u][t], dH2[u][tk], Wb[t], st);
+                }
+#pragma unroll
+                for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        dH1p[u][t] = P::masked(d[u][t], H1p[u][t]);
+                        gb1[t] += P::sum(dH1p[u][t]);
+                    }
+            }
+            {
+                const KB Id = blk(B_ID);
+                f32x16 tX[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) tX[u] = splat(0.f);
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) P::mma_step(tX[u], X[u], Id, st);
+#pragma unroll
+                for (int u = 0; u < U; ++u) Xp[u] = P::cast(tX[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int st = 0; st < P::kSteps; ++st)
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t) P::mma_step(gW1[t], dH1p[u][t], Xp[u], st);
         }
     }
 
@@ -773,27 +951,22 @@ int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, 
     hipStream_t st = as_stream(stream);
 #ifdef MI3D_DEV
     const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
-    if (half_mode && variant == 1) {
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+    if (half_mode && variant == 1) {  // one tile at a time
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
                            n, w, dx, dx_plane_rows, level_absmax, g);
         return (int)hipGetLastError();
     }
-    if (half_mode && variant == 2) {
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, level_absmax, g);
-        return (int)hipGetLastError();
-    }
-    if (half_mode && variant == 3) {
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+    if (half_mode && variant == 2) {  // one tile at a time, two waves per SIMD (256 registers, spills)
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 2>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
                            n, w, dx, dx_plane_rows, level_absmax, g);
         return (int)hipGetLastError();
     }
 #endif
     if (half_mode)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
                            n, w, dx, dx_plane_rows, level_absmax, g);
     else
-        hipLaunchKernelGGL((k_mlp_backward<F32, 1, true>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, dout,
+        hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, dout,
                            n, w, dx, dx_plane_rows, level_absmax, g);
     return (int)hipGetLastError();
 }

@@ -141,14 +141,30 @@ struct EncodeSeg { uint32_t level, tile0, tile1; };
 struct EncodePlan {
     uint32_t n_seg[kXcds];
     EncodeSeg seg[kXcds][kMaxSegs];
+    uint32_t nt_mask;  // levels gathered with non-temporal loads (every lane in its own line: nothing for the L1 to keep)
 };
 
-template <bool PAIR>
+using nf2 = __attribute__((ext_vector_type(2))) float;
+using nf4 = __attribute__((ext_vector_type(4))) float;
+template <class T, bool NT> __device__ __forceinline__ T gload(const T *p);
+template <> __device__ __forceinline__ float2 gload<float2, false>(const float2 *p) { return *p; }
+template <> __device__ __forceinline__ float4 gload<float4, false>(const float4 *p) { return *p; }
+template <> __device__ __forceinline__ float2 gload<float2, true>(const float2 *p) {
+    const nf2 t = __builtin_nontemporal_load(reinterpret_cast<const nf2 *>(p));
+    return make_float2(t[0], t[1]);
+}
+template <> __device__ __forceinline__ float4 gload<float4, true>(const float4 *p) {
+    const nf4 t = __builtin_nontemporal_load(reinterpret_cast<const nf4 *>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <bool PAIR, bool NT>
 __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 *__restrict__ lvl, uint32_t cx,
                                                uint32_t cy, uint32_t cz, float2 (&v)[8]) {
     if (!PAIR) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) v[k] = lvl[grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))];
+        for (uint32_t k = 0; k < 8; ++k)
+            v[k] = gload<float2, NT>(lvl + grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2)));
         return;
     }
     uint32_t e0[4], e1[4];
@@ -158,11 +174,11 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
         e0[j] = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
         e1[j] = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
         // the aligned 16-byte slot holding entry e0 (level bases and sizes are multiples of 8 entries)
-        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u));
+        t[j] = gload<float4, NT>(reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u)));
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j)  // the x+1 corner only where it is not the other half of that slot
-        if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = lvl[e1[j]];
+        if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = gload<float2, NT>(lvl + e1[j]);
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const bool odd = e0[j] & 1u;
@@ -185,6 +201,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
         float2 *plane = planes + (size_t)l * rows_total;
+        const bool nt = (plan.nt_mask >> l) & 1u;
         for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
             const uint32_t s = tile * kTile + lane;
             if (s >= n) continue;
@@ -199,7 +216,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                 grid_cell(q[1], L.scale, cy, fy);
                 grid_cell(q[2], L.scale, cz, fz);
                 float2 v[8];
-                gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
+                if (nt) gather_corners<PAIR, true>(L, lvl, cx, cy, cz, v);
+                else gather_corners<PAIR, false>(L, lvl, cx, cy, cz, v);
                 const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
                 // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
@@ -227,11 +245,12 @@ inline double encode_level_cost(double x) {
 }
 
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
-inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level) {
+inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level, bool nt_levels) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale);
+        if (nt_levels && (double)step01 * (double)T.level[l].scale >= 0.7) plan.nt_mask |= 1u << l;
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
         total += cost[l];
     }
@@ -1117,7 +1136,8 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const uint32_t tiles = (n + kTile - 1) / kTile;
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
+    const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 1);
+    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1), (variant & 2) != 0);
     uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
     const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
     const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU
@@ -1126,7 +1146,7 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const float2 *tab = reinterpret_cast<const float2 *>(params);
     float2 *out = reinterpret_cast<float2 *>(out_planes);
     hipStream_t st = as_stream(stream);
-    if (MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 1) & 1)
+    if (variant & 1)
         hipLaunchKernelGGL((k_grid_encode_planes<true>), grid, block, 0, st, ps, n, tab, T, plan, out);
     else
         hipLaunchKernelGGL((k_grid_encode_planes<false>), grid, block, 0, st, ps, n, tab, T, plan, out);

@@ -74,7 +74,7 @@ def main():
         tune(T_ENCODE_VARIANT, 0)
         encode()
         ref = feats.clone()
-        for v in (0, 1):
+        for v in (0, 1, 3):
             tune(T_ENCODE_VARIANT, v)
             feats.zero_()
             ms = timeit(encode, a.iters)
@@ -87,7 +87,7 @@ def main():
             res[f"encode_v1_wgs{w}_ms"] = timeit(encode, a.iters)
         tune(T_ENCODE_WGS, -1)
     if "levels" in what:
-        for v in (0, 1):
+        for v in (1, 3):
             tune(T_ENCODE_VARIANT, v)
             per = []
             for l in range(16):
@@ -114,9 +114,9 @@ def main():
         def bwd(rows=P * n):
             L.call("mi3d_mlp_backward", L.ptr(feats), P * n, L.ptr(dh), rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1,
                    L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream())
-        for v in (0, 1, 2, 3):   # 0: 1 wave/SIMD + prefetch, 1: 2 waves/SIMD + prefetch, 2: 2 waves no prefetch, 3: 1 wave no prefetch
+        for v in (0, 1, 2):   # 0: two tiles per wave (staged), 1: one tile per wave, 2: one tile, 2 waves/SIMD (spills)
             tune(6, v)
-            for w in ((2, 4) if v in (1, 2) else (2,)):
+            for w in ((2, 4) if v == 2 else (1, 2)):
                 tune(T_MLP_WGS, w)
                 res[f"mlp_bwd_variant{v}_wgs{w}_ms"] = timeit(bwd, a.iters)
         tune(6, -1)
