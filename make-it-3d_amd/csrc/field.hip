@@ -87,18 +87,24 @@ struct F16 {
         }
         return k;
     }
-    // gradient tile masked by the ReLU of `act` (a K-block from relu()): convert, AND with 0xFFFF where act != 0
+    // gradient tile masked by the ReLU of `act` (a K-block from relu()): packed convert, then per binary16 lane
+    // AND with 0xFFFF where act != 0 - min(act, 1) * 0xFFFF in packed u16 arithmetic.  (Written as inline asm: the
+    // optimiser canonicalises every C spelling of it into 16 compares + 16 selects + 16 scalar converts per K-block,
+    // which made the masks a third of the kernel's instructions.)
     __device__ static __forceinline__ KB masked(const f32x16 &d, const KB &act) {
         KB k;
+        const unsigned ones = 0x00010001u, full = 0xFFFFFFFFu;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            half8 hv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) hv[i] = (_Float16)d[8 * u + i];
-            const ushort8v bits = __builtin_bit_cast(ushort8v, act.v[u]);
-            const ushort8v one = {1, 1, 1, 1, 1, 1, 1, 1};
-            const ushort8v m = (ushort8v)(0) - __builtin_elementwise_min(bits, one);  // 0xFFFF where act != 0
-            k.v[u] = __builtin_bit_cast(half8, (ushort8v)(__builtin_bit_cast(ushort8v, hv) & m));
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 pr = {d[2 * j], d[2 * j + 1]};
+            const half2v hv = __builtin_convertvector(pr, half2v);
+            const half2v av = {act.v[j >> 2][2 * (j & 3)], act.v[j >> 2][2 * (j & 3) + 1]};
+            unsigned m = __builtin_bit_cast(unsigned, av), dv = __builtin_bit_cast(unsigned, hv);
+            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %3\n\tv_and_b32 %0, %0, %4"
+                : "=&v"(m) : "v"(m), "s"(ones), "s"(full), "v"(dv));
+            const half2v r = __builtin_bit_cast(half2v, m);
+            k.v[j >> 2][2 * (j & 3)] = r[0];
+            k.v[j >> 2][2 * (j & 3) + 1] = r[1];
         }
         return k;
     }

@@ -121,19 +121,20 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 // Output is level-major planes [L][P*n][2], row = p*n + s (point-major): the 64 lanes of a wave store 512 contiguous
 // bytes per point, and the MLP kernels read them with x_plane_rows = P*n.
 //
-// What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level): levels 0-7 cost 1.3-1.5 ms each,
-// then the cost climbs with the number of distinct lines a wave's 64 consecutive samples touch - 1.7 / 2.1 / 2.6 / 3.2 /
-// 3.8 ms for levels 8-12 - and saturates at 4.06 ms for levels 13-15, where every lane is in its own line:
-// 141 M evaluations x 8 corners x one 128-byte line from the L2 = 145 GB per level against the L2s' ~34.5 TB/s
-// (MI355X_MICROARCH.md) = 4.2 ms.  The gather is L2->L1 line-bandwidth bound (16x the bytes it uses), the sum over the
-// levels is 36 ms when the XCDs are evenly loaded - which the segments below are for - and the only bytes that can be
-// saved are the second lookup of a line:
+// What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level, profiles/kbench_r02.json): levels 0-7
+// cost 1.15-1.3 ms each, then the cost climbs with the number of distinct lines a wave's 64 consecutive samples touch -
+// 1.6 / 2.0 / 2.6 / 3.3 / 3.6 ms for levels 8-12 - and saturates at 3.8 ms (4.06 without pair loads) for levels 13-15,
+// where every lane is in its own line: 141 M evaluations x 8 corners x one 128-byte line from the L2 = 145 GB per level
+// against the L2s' ~34.5 TB/s (MI355X_MICROARCH.md) = 4.2 ms.  The gather is L2->L1 line-bandwidth bound (16x the bytes
+// it uses); the levels sum to 34 ms, the launch takes 39.5 ms with the segments below.
+// Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
+// per CU (+3 ms); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the coarse
+// levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
+// What is kept:
 //   PAIR   the x and x+1 corners of a (y, z) corner pair are neighbours in memory whenever their entry indices differ
 //          in bit 0 only - every even cx on hashed levels (x enters the hash with prime 1), every even entry index on
 //          dense ones: one 16-byte load of the aligned slot serves both, the x+1 corner is fetched separately only
-//          where the pair straddles a slot (measured: -10 % on the saturated levels).
-// (Keeping the corner values of the sample's own cell in registers for its +-eps neighbours was measured too: the
-// coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower.)
+//          where the pair straddles a slot (-10 % on the saturated levels, 44.7 -> 39.5 ms per launch).
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
 
@@ -141,30 +142,15 @@ struct EncodeSeg { uint32_t level, tile0, tile1; };
 struct EncodePlan {
     uint32_t n_seg[kXcds];
     EncodeSeg seg[kXcds][kMaxSegs];
-    uint32_t nt_mask;  // levels gathered with non-temporal loads (every lane in its own line: nothing for the L1 to keep)
 };
 
-using nf2 = __attribute__((ext_vector_type(2))) float;
-using nf4 = __attribute__((ext_vector_type(4))) float;
-template <class T, bool NT> __device__ __forceinline__ T gload(const T *p);
-template <> __device__ __forceinline__ float2 gload<float2, false>(const float2 *p) { return *p; }
-template <> __device__ __forceinline__ float4 gload<float4, false>(const float4 *p) { return *p; }
-template <> __device__ __forceinline__ float2 gload<float2, true>(const float2 *p) {
-    const nf2 t = __builtin_nontemporal_load(reinterpret_cast<const nf2 *>(p));
-    return make_float2(t[0], t[1]);
-}
-template <> __device__ __forceinline__ float4 gload<float4, true>(const float4 *p) {
-    const nf4 t = __builtin_nontemporal_load(reinterpret_cast<const nf4 *>(p));
-    return make_float4(t[0], t[1], t[2], t[3]);
-}
-
-template <bool PAIR, bool NT>
+template <bool PAIR>
 __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 *__restrict__ lvl, uint32_t cx,
                                                uint32_t cy, uint32_t cz, float2 (&v)[8]) {
     if (!PAIR) {
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            v[k] = gload<float2, NT>(lvl + grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2)));
+            v[k] = lvl[grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))];
         return;
     }
     uint32_t e0[4], e1[4];
@@ -174,11 +160,11 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
         e0[j] = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
         e1[j] = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
         // the aligned 16-byte slot holding entry e0 (level bases and sizes are multiples of 8 entries)
-        t[j] = gload<float4, NT>(reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u)));
+        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u));
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j)  // the x+1 corner only where it is not the other half of that slot
-        if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = gload<float2, NT>(lvl + e1[j]);
+        if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = lvl[e1[j]];
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const bool odd = e0[j] & 1u;
@@ -201,7 +187,6 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
         float2 *plane = planes + (size_t)l * rows_total;
-        const bool nt = (plan.nt_mask >> l) & 1u;
         for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
             const uint32_t s = tile * kTile + lane;
             if (s >= n) continue;
@@ -216,8 +201,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                 grid_cell(q[1], L.scale, cy, fy);
                 grid_cell(q[2], L.scale, cz, fz);
                 float2 v[8];
-                if (nt) gather_corners<PAIR, true>(L, lvl, cx, cy, cz, v);
-                else gather_corners<PAIR, false>(L, lvl, cx, cy, cz, v);
+                gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
                 const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
                 // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
@@ -236,7 +220,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
 inline double encode_level_cost(double x) {
     static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
-    static const double cs[] = {1.30, 1.32, 1.40, 1.51, 1.66, 1.95, 2.45, 3.15, 3.55, 3.65, 3.67, 3.67};
+    static const double cs[] = {1.17, 1.18, 1.22, 1.31, 1.56, 2.00, 2.64, 3.26, 3.63, 3.75, 3.80, 3.79};
     constexpr int N = sizeof(xs) / sizeof(xs[0]);
     if (x <= xs[0]) return cs[0];
     for (int i = 1; i < N; ++i)
@@ -245,12 +229,11 @@ inline double encode_level_cost(double x) {
 }
 
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
-inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level, bool nt_levels) {
+inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale);
-        if (nt_levels && (double)step01 * (double)T.level[l].scale >= 0.7) plan.nt_mask |= 1u << l;
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
         total += cost[l];
     }
@@ -1137,7 +1120,7 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const uint32_t tiles = (n + kTile - 1) / kTile;
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 1);
-    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1), (variant & 2) != 0);
+    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
     uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
     const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
     const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU

@@ -74,7 +74,7 @@ def main():
         tune(T_ENCODE_VARIANT, 0)
         encode()
         ref = feats.clone()
-        for v in (0, 1, 3):
+        for v in (0, 1):
             tune(T_ENCODE_VARIANT, v)
             feats.zero_()
             ms = timeit(encode, a.iters)
@@ -87,7 +87,7 @@ def main():
             res[f"encode_v1_wgs{w}_ms"] = timeit(encode, a.iters)
         tune(T_ENCODE_WGS, -1)
     if "levels" in what:
-        for v in (1, 3):
+        for v in (1,):
             tune(T_ENCODE_VARIANT, v)
             per = []
             for l in range(16):

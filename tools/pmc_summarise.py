@@ -4,7 +4,8 @@ Every CSV is one --pmc pass of tools/field_bench.py (FETCH_SIZE and WRITE_SIZE n
 kernel family the per-launch averages of every counter are recorded, plus
   hbm_bytes_per_eval = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / evals   (gfx950: FETCH_SIZE counts wide reads at half
                        their bytes, /opt/skills/guides/MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported)
-  mfma_busy_frac     = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)
+  mfma_busy_frac     = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs)   (rocprofv3 sums
+                       GRBM_GUI_ACTIVE over the 8 XCDs: 288.8 M for a 16.0 ms launch at ~2.1 GHz = 8 x 36 M)
   lds_conflict_frac  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 Only the LARGEST launches of a family (>= half of its maximum grid-independent duration proxy: the counter itself)
 would skew nothing here: the two backward passes differ 13x in size, so families are split by launch size into
@@ -60,7 +61,7 @@ def main():
             rec["evals_per_launch"] = evals
             rec["hbm_bytes_per_eval"] = (rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]) / evals
         if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("GRBM_GUI_ACTIVE"):
-            rec["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") * 256 * 4)
+            rec["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8.0 * 256 * 4)
         if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
             rec["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
         db.setdefault(fam, {})[workload] = rec
