@@ -98,6 +98,32 @@ int mi3d_composite_sdf_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, i
                             float *rays_t, const float *sigmas, const float *rgbs, const float *deltas,
                             float *weights_sum, float *depth, float *image, void *stream);
 
+/* ---- Part 1b: the inference loop driven from the device (replaces the host logic of nerf/renderer.py:526-551).
+ * The reference loop reads the number of alive rays back every round (a boolean-mask copy = a synchronisation)
+ * because launch sizes and n_step = max(min(N / n_alive, 8), 1) depend on it.  Here that state lives in `ctl`
+ * (device int32[8]: [0] n_alive, [1] n_step, [2] rows = n_alive*n_step rounded up PAST a multiple of `align` as
+ * raymarching.py:397-400 does, [3] marching steps done, [4] rounds done) and the kernels of a round read it; the host
+ * launches each round for an upper bound `n_alive_max` of the alive count and may look at ctl[0] as rarely as it likes.
+ *   mi3d_infer_begin        rays_alive = 0..N-1, ctl planned for round 0
+ *   mi3d_march_rays_ctl     = mi3d_march_rays for ctl's n_alive / n_step; rows a ray leaves unused and the alignment
+ *                             rows are zeroed (buffers of N + align rows are re-used across rounds); `noises` (float[N]
+ *                             or NULL) jitters round 0 only (renderer.py:546)
+ *   mi3d_composite_rays_ctl = mi3d_composite_rays for ctl's n_alive / n_step
+ *   mi3d_compact_alive_ctl  rays_alive_out = the entries >= 0 of rays_alive_in[0 .. n_alive), order kept (the boolean
+ *                             mask of renderer.py:550); ctl advanced: steps += n_step, n_alive = 0 once steps >=
+ *                             max_steps (`while step < max_steps`), next round planned */
+int mi3d_infer_begin(int32_t *ctl, int32_t *rays_alive, uint32_t N, uint32_t align, void *stream);
+int mi3d_march_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, const int32_t *rays_alive, const float *rays_t,
+                        const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, float *xyzs, float *dirs,
+                        float *deltas, const float *noises, void *stream);
+int mi3d_composite_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_thresh, int32_t *rays_alive,
+                            float *rays_t, const float *sigmas, const float *rgbs, const float *normals,
+                            const float *deltas, float *weights_sum, float *depth, float *image, float *normal,
+                            void *stream);
+int mi3d_compact_alive_ctl(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
+                           uint32_t align, uint32_t max_steps, void *stream);
+
 /* ------------------------------------------------------------------ Part 2: hash-grid encoding */
 
 /* Level table of a tcnn HashGrid (host side; no device work).  offsets_host has n_levels+1 entries in
@@ -215,6 +241,23 @@ int mi3d_field_head_backward(const float *h, const float *x, const float *x2, ui
                              uint32_t P, uint32_t P_active, float bound, float blob_density, float blob_radius,
                              float epsilon, const float *dsigma, const float *dalbedo, const float *dnormal,
                              const float *dnormal2, float *dh, void *stream);
+
+/* ------------------------------------------------------------------ Part 6: the optimizer step */
+
+/* Adan as the reference configures it (main.py:132; optimizer.py:100-249 `Adan.step` + `_single_tensor_adan`), one
+ * fused elementwise pass per parameter tensor, in the reference's operation order.  All pointers are device fp32
+ * arrays of `count` elements, 16-byte aligned; grad is scaled by the clip factor in place (as the reference does),
+ * the four state arrays are updated in place (the caller zero-initialises exp_avg / exp_avg_sq / exp_avg_diff once;
+ * neg_pre_grad is initialised here when first_step != 0).
+ * The global-norm clip stays on the device: call mi3d_sumsq_accumulate on every gradient tensor into ONE zeroed device
+ * float, pass it as grad_sumsq; clip = min(max_grad_norm / (sqrt(sum) + clip_eps), 1) (optimizer.py:107-127, without
+ * its `.item()` host sync).  grad_sumsq == NULL or max_grad_norm <= 0: no clipping. */
+int mi3d_sumsq_accumulate(const float *x, size_t n, float *acc, void *stream);
+int mi3d_adan_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *exp_avg_diff,
+                   float *neg_pre_grad, size_t count, const float *grad_sumsq, float max_grad_norm, float clip_eps,
+                   int first_step, float beta1, float beta2, float beta3, float bias_correction1,
+                   float bias_correction2, float bias_correction3_sqrt, float lr, float weight_decay, float eps,
+                   int no_prox, void *stream);
 
 #ifdef __cplusplus
 }

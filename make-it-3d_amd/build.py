@@ -19,6 +19,7 @@ UNITS = [
     ("raymarching.hip", ["-ffp-contract=off"]),
     ("hashgrid.hip", []),
     ("field.hip", []),
+    ("optim.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["mi3d_common.h", "mi3d_grid.h", os.path.join("..", "..", "include", "mi3d.h")]
 

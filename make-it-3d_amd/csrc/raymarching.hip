@@ -347,15 +347,13 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(
 
 // ---------------------------------------------------------------- inference (one thread per alive ray)
 
-__global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
-                              const float *__restrict__ rays_t, const float *__restrict__ rays_o,
-                              const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
-                              uint32_t C, uint32_t H, const uint8_t *__restrict__ bits,
-                              const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
-                              float *__restrict__ deltas, const float *__restrict__ noises) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
-    const int32_t index = rays_alive[n];
+// March up to n_step occupied steps of ray `index` into slot n of the round's sample buffers.  zero_tail: the rows a
+// finished ray leaves unused are zeroed here (the ctl loop re-uses its buffers; the reference op gets fresh torch.zeros)
+__device__ __forceinline__ void march_infer_ray(uint32_t n, int32_t index, uint32_t n_step, const float *rays_t,
+                                                const float *rays_o, const float *rays_d, float bound, float dt_gamma,
+                                                uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *bits,
+                                                const float *fars, float *xyzs, float *dirs, float *deltas, float noise,
+                                                bool zero_tail) {
     MarchGrid g;
     march_grid_init(g, bits, bound, dt_gamma, max_steps, C, H);
     MarchRay r;
@@ -363,7 +361,7 @@ __global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t *
     const float far = fars[index];
     float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3,
           *pl = deltas + (size_t)n * n_step * 2;
-    float t = march_t0(rays_t[index], noises[n], g);
+    float t = march_t0(rays_t[index], noise, g);
     float last_t = t, x, y, z, dt;
     uint32_t step = 0;
     while (t < far && step < n_step) {
@@ -377,16 +375,32 @@ __global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t *
             ++step;
         }
     }
+    if (zero_tail)
+        for (; step < n_step; ++step) {
+            px[0] = px[1] = px[2] = 0.f; pd[0] = pd[1] = pd[2] = 0.f; pl[0] = pl[1] = 0.f;
+            px += 3; pd += 3; pl += 2;
+        }
+}
+
+__global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                              const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                              const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                              uint32_t C, uint32_t H, const uint8_t *__restrict__ bits,
+                              const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                              float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    march_infer_ray(n, rays_alive[n], n_step, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bits, fars, xyzs,
+                    dirs, deltas, noises[n], false);
 }
 
 template <bool SDF>
-__global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
-                                  float *__restrict__ rays_t, const float *__restrict__ sigmas,
-                                  const float *__restrict__ rgbs, const float *__restrict__ normals,
-                                  const float *__restrict__ deltas, float *__restrict__ weights_sum,
-                                  float *__restrict__ depth, float *__restrict__ image, float *__restrict__ normal) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
+__device__ __forceinline__ void composite_infer_ray(uint32_t n, uint32_t n_step, float T_thresh,
+                                                    int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                    const float *__restrict__ normals, const float *__restrict__ deltas,
+                                                    float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                    float *__restrict__ image, float *__restrict__ normal) {
     const int32_t index = rays_alive[n];
     const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3,
                 *dl = deltas + (size_t)n * n_step * 2;
@@ -417,6 +431,124 @@ __global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thr
     depth[index] = d;
     image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
     if (!SDF) { normal[(size_t)index * 3] = nx; normal[(size_t)index * 3 + 1] = ny; normal[(size_t)index * 3 + 2] = nz; }
+}
+
+template <bool SDF>
+__global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                                  float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                  const float *__restrict__ rgbs, const float *__restrict__ normals,
+                                  const float *__restrict__ deltas, float *__restrict__ weights_sum,
+                                  float *__restrict__ depth, float *__restrict__ image, float *__restrict__ normal) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    composite_infer_ray<SDF>(n, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth,
+                             image, normal);
+}
+
+// ---------------------------------------------------------------- inference loop driven from the device
+// The reference's eval loop (nerf/renderer.py:526-551) asks the HOST for the number of alive rays every round
+// (`rays_alive = rays_alive[rays_alive >= 0]` is a boolean-mask copy = a device synchronisation) because the round's
+// launch sizes and n_step = max(min(N // n_alive, 8), 1) depend on it.  Here that state lives in a device control
+// block and every kernel of a round reads it: the host launches rounds for an upper bound of the alive count and looks
+// at the real one only every few rounds.
+//   ctl[0] n_alive   ctl[1] n_step   ctl[2] rows = n_alive * n_step rounded up past `align` (raymarching.py:397-400)
+//   ctl[3] marching steps done so far (the loop's `step`)   ctl[4] rounds done
+enum : int { CTL_ALIVE = 0, CTL_STEP = 1, CTL_ROWS = 2, CTL_DONE = 3, CTL_ROUNDS = 4, CTL_SIZE = 8 };
+
+__device__ __forceinline__ void infer_plan(int32_t n_alive, uint32_t N, uint32_t align, int32_t *ctl) {
+    int32_t n_step = 0, rows = 0;
+    if (n_alive > 0) {
+        n_step = (int32_t)(N / (uint32_t)n_alive);
+        n_step = n_step > 8 ? 8 : (n_step < 1 ? 1 : n_step);
+        rows = n_alive * n_step;
+        if (align > 0) rows += (int32_t)align - rows % (int32_t)align;
+    }
+    ctl[CTL_ALIVE] = n_alive; ctl[CTL_STEP] = n_step; ctl[CTL_ROWS] = rows;
+}
+
+__global__ void k_infer_begin(int32_t *__restrict__ ctl, int32_t *__restrict__ rays_alive, uint32_t N, uint32_t align) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) rays_alive[i] = (int32_t)i;
+    if (i == 0) {
+        infer_plan((int32_t)N, N, align, ctl);
+        ctl[CTL_DONE] = 0; ctl[CTL_ROUNDS] = 0;
+    }
+}
+
+__global__ void k_march_infer_ctl(const int32_t *__restrict__ ctl, const int32_t *__restrict__ rays_alive,
+                                  const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                  const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                  uint32_t C, uint32_t H, const uint8_t *__restrict__ bits,
+                                  const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                  float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n_alive = (uint32_t)ctl[CTL_ALIVE], n_step = (uint32_t)ctl[CTL_STEP], rows = (uint32_t)ctl[CTL_ROWS];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_alive) {
+        // the jitter applies to the first round only (renderer.py:546: `perturb if step == 0 else False`)
+        const float noise = (noises != nullptr && ctl[CTL_ROUNDS] == 0) ? noises[n] : 0.f;
+        march_infer_ray(n, rays_alive[n], n_step, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bits, fars,
+                        xyzs, dirs, deltas, noise, true);
+    }
+    // the alignment rows behind the last ray read as finished samples
+    for (uint32_t r = n_alive * n_step + n; r < rows; r += gridDim.x * blockDim.x) {
+        xyzs[(size_t)r * 3] = xyzs[(size_t)r * 3 + 1] = xyzs[(size_t)r * 3 + 2] = 0.f;
+        dirs[(size_t)r * 3] = dirs[(size_t)r * 3 + 1] = dirs[(size_t)r * 3 + 2] = 0.f;
+        deltas[(size_t)r * 2] = deltas[(size_t)r * 2 + 1] = 0.f;
+    }
+}
+
+__global__ void k_composite_infer_ctl(const int32_t *__restrict__ ctl, float T_thresh, int32_t *__restrict__ rays_alive,
+                                      float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                      const float *__restrict__ rgbs, const float *__restrict__ normals,
+                                      const float *__restrict__ deltas, float *__restrict__ weights_sum,
+                                      float *__restrict__ depth, float *__restrict__ image, float *__restrict__ normal) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (uint32_t)ctl[CTL_ALIVE]) return;
+    composite_infer_ray<false>(n, (uint32_t)ctl[CTL_STEP], T_thresh, rays_alive, rays_t, sigmas, rgbs, normals, deltas,
+                               weights_sum, depth, image, normal);
+}
+
+// Order-preserving compaction of the rays still alive (entries >= 0) - what the boolean mask does - by ONE 1024-thread
+// workgroup (N is a few 10^4): wave64 ballot ranks inside a wave, an LDS scan over the 16 waves, a running base across
+// chunks.  The same kernel advances the loop state and plans the next round.
+__global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict__ ctl, const int32_t *__restrict__ in,
+                                                            int32_t *__restrict__ out, uint32_t N, uint32_t align,
+                                                            uint32_t max_steps) {
+    __shared__ uint32_t wave_count[16];
+    __shared__ uint32_t base_s;
+    const uint32_t n_alive = (uint32_t)ctl[CTL_ALIVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_alive; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const int32_t v = i < n_alive ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = wave_count[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        const uint32_t base = base_s;
+        if (keep) out[base + before + rank] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int32_t done = ctl[CTL_DONE] + ctl[CTL_STEP];
+        int32_t alive = (int32_t)base_s;
+        if (done >= (int32_t)max_steps) alive = 0;  // `while step < max_steps` of the reference loop
+        infer_plan(alive, N, align, ctl);
+        ctl[CTL_DONE] = done;
+        ctl[CTL_ROUNDS] += 1;
+    }
 }
 
 }  // namespace
@@ -534,6 +666,41 @@ int mi3d_composite_sdf_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, i
     hipLaunchKernelGGL(k_composite_infer<true>, dim3(cdiv(n_alive, 128)), dim3(128), 0, as_stream(stream), n_alive,
                        n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, nullptr, deltas, weights_sum, depth, image,
                        nullptr);
+    return launch_status();
+}
+
+/* ---- inference loop driven from the device (see k_infer_begin .. k_compact_alive_ctl above) */
+int mi3d_infer_begin(int32_t *ctl, int32_t *rays_alive, uint32_t N, uint32_t align, void *stream) {
+    if (N == 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_infer_begin, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), ctl, rays_alive, N, align);
+    return launch_status();
+}
+
+int mi3d_march_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, const int32_t *rays_alive, const float *rays_t,
+                        const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, float *xyzs, float *dirs,
+                        float *deltas, const float *noises, void *stream) {
+    if (n_alive_max == 0) return 0;
+    hipLaunchKernelGGL(k_march_infer_ctl, dim3(cdiv(n_alive_max, 128)), dim3(128), 0, as_stream(stream), ctl, rays_alive,
+                       rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    return launch_status();
+}
+
+int mi3d_composite_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_thresh, int32_t *rays_alive,
+                            float *rays_t, const float *sigmas, const float *rgbs, const float *normals,
+                            const float *deltas, float *weights_sum, float *depth, float *image, float *normal,
+                            void *stream) {
+    if (n_alive_max == 0) return 0;
+    hipLaunchKernelGGL(k_composite_infer_ctl, dim3(cdiv(n_alive_max, 128)), dim3(128), 0, as_stream(stream), ctl, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth, image, normal);
+    return launch_status();
+}
+
+int mi3d_compact_alive_ctl(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
+                           uint32_t align, uint32_t max_steps, void *stream) {
+    if (N == 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_compact_alive_ctl, dim3(1), dim3(1024), 0, as_stream(stream), ctl, rays_alive_in, rays_alive_out,
+                       N, align, max_steps);
     return launch_status();
 }
 

@@ -32,6 +32,10 @@ _SIGNATURES = {
     "mi3d_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "mi3d_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mi3d_composite_sdf_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_infer_begin": [vp, vp, u32, u32, vp],
+    "mi3d_march_rays_ctl": [vp, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_composite_rays_ctl": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_compact_alive_ctl": [vp, vp, vp, u32, u32, u32, vp],
     # Part 2 ------------------------------------------------------------------------------------------
     "mi3d_hashgrid_forward": [vp, u32, vp, u32, u32, f32, u32, vp, vp],
     "mi3d_hashgrid_backward": [vp, u32, vp, u32, u32, f32, u32, vp, vp],
@@ -47,6 +51,10 @@ _SIGNATURES = {
     # Part 5 ------------------------------------------------------------------------------------------
     "mi3d_field_head_forward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
     "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    # Part 6 ------------------------------------------------------------------------------------------
+    "mi3d_sumsq_accumulate": [vp, C.c_size_t, vp, vp],
+    "mi3d_adan_step": [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, f32, f32, i32, f32, f32, f32, f32, f32, f32, f32, f32, f32,
+                       i32, vp],
 }
 
 

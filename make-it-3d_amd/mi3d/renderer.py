@@ -181,7 +181,7 @@ class NeRFRenderer(nn.Module):
     def run_cuda(self, rays_o, rays_d, depth_scale=None, bg_color=None, dt_gamma=0, light_d=None, ambient_ratio=1.0,
                  shading="albedo", perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         """renderer.py:481-583.  Training: march -> field (13-point stencil) -> composite + normal regularisers.
-        Eval: the march/composite loop over alive rays."""
+        Eval: the march/composite loop over alive rays, its round state kept on the device."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -216,23 +216,37 @@ class NeRFRenderer(nn.Module):
             depth = torch.zeros(N, dtype=torch.float32, device=device)
             image = torch.zeros(N, 3, dtype=torch.float32, device=device)
             normal = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+            # The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list - kept
+            # on the DEVICE (raymarching.*_ctl, C ABI Part 1b): every round is launched for an upper bound of the alive
+            # count and the real one is read back only every `sync_every` rounds, instead of one boolean-mask
+            # synchronisation per round.  Same arithmetic, same round structure, same results.
             rays_t = nears.clone()
-            step = 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
-                                                            self.bound, self.density_bitfield, self.cascade,
-                                                            self.grid_size, nears, fars, 128,
-                                                            perturb if step == 0 else False, dt_gamma, max_steps)
-                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, (normals + 1) / 2,
-                                           deltas, weights_sum, depth, image, normal, T_thresh)
-                rays_alive = rays_alive[rays_alive >= 0]
-                step += n_step
+            align, sync_every = 128, 4
+            rows_cap = N + 2 * align
+            xyzs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
+            dirs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
+            deltas = torch.zeros(rows_cap, 2, dtype=torch.float32, device=device)
+            noises = torch.rand(N, dtype=torch.float32, device=device) if perturb else None
+            ctl, alive = raymarching.infer_begin(N, device, align)
+            spare = torch.empty_like(alive)
+            n_ub, done_lb, rounds = N, 0, 0
+            while n_ub > 0 and done_lb < max_steps:
+                rows_ub = min(N, 8 * n_ub)
+                rows_ub += align - rows_ub % align       # >= the device's n_alive * n_step rounded past `align`
+                raymarching.march_rays_ctl(ctl, n_ub, alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
+                                           self.cascade, self.grid_size, fars, xyzs, dirs, deltas, noises, dt_gamma,
+                                           max_steps)
+                sigmas, rgbs, normals = self(xyzs[:rows_ub], dirs[:rows_ub], light_d, ratio=ambient_ratio,
+                                             shading=shading)
+                raymarching.composite_rays_ctl(ctl, n_ub, alive, rays_t, sigmas, rgbs, (normals + 1) / 2,
+                                               deltas[:rows_ub], weights_sum, depth, image, normal, T_thresh)
+                raymarching.compact_alive_ctl(ctl, alive, spare, N, align, max_steps)
+                alive, spare = spare, alive
+                done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
+                rounds += 1
+                if rounds % sync_every == 0:
+                    state = ctl.tolist()                 # the only synchronisation: every `sync_every` rounds
+                    n_ub, done_lb = state[0], state[3]
 
         if bg_color is None:
             bg_color = 1

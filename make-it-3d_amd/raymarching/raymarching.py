@@ -301,3 +301,47 @@ class _composite_sdf_rays(Function):
 
 
 composite_sdf_rays = _composite_sdf_rays.apply
+
+
+# ---------------------------------------------------------------------------- inference loop driven from the device
+# Extensions beyond the reference's op surface (C ABI Part 1b): the state the reference's eval loop keeps on the host
+# (n_alive, n_step; nerf/renderer.py:526-551) lives in a device control block, so a round needs no synchronisation.
+# mi3d.renderer.NeRFRenderer.run_cuda uses them; the reference's own loop keeps working on march_rays / composite_rays.
+
+
+def infer_begin(N, device, align=128):
+    """(ctl int32[8], rays_alive int32[N] = 0..N-1) for a fresh loop over N rays."""
+    ctl = torch.zeros(8, dtype=torch.int32, device=device)
+    rays_alive = torch.empty(N, dtype=torch.int32, device=device)
+    L.launch("mi3d_infer_begin", ctl, L.ptr(ctl), L.ptr(rays_alive), int(N), int(max(align, 0)))
+    return ctl, rays_alive
+
+
+def march_rays_ctl(ctl, n_alive_max, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, fars, xyzs, dirs,
+                   deltas, noises=None, dt_gamma=0, max_steps=1024):
+    """march_rays for the device-side n_alive / n_step of `ctl`, into caller-owned buffers of >= N + align rows."""
+    rays_o, rays_d = _rays(rays_o, rays_d)
+    bits = L.dev_typed(density_bitfield, "density_bitfield", torch.uint8)
+    L.launch("mi3d_march_rays_ctl", rays_o, L.ptr(L.dev_typed(ctl, "ctl", torch.int32)), int(n_alive_max),
+             L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")), L.ptr(rays_o),
+             L.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), int(C), int(H), L.ptr(bits),
+             L.ptr(L.dev_f32(fars, "fars")), L.ptr(L.dev_f32(xyzs, "xyzs", 3)), L.ptr(L.dev_f32(dirs, "dirs", 3)),
+             L.ptr(L.dev_f32(deltas, "deltas", 2)), L.ptr(noises))
+
+
+def composite_rays_ctl(ctl, n_alive_max, rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth, image,
+                       normal, T_thresh=1e-2):
+    sigmas = L.dev_f32(sigmas.float().contiguous(), "sigmas")
+    rgbs = L.dev_f32(rgbs.float().contiguous(), "rgbs")
+    normals = L.dev_f32(normals.float().contiguous(), "normals")
+    L.launch("mi3d_composite_rays_ctl", sigmas, L.ptr(ctl), int(n_alive_max), float(T_thresh),
+             L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")), L.ptr(sigmas),
+             L.ptr(rgbs), L.ptr(normals), L.ptr(L.dev_f32(deltas, "deltas")), L.ptr(L.dev_f32(weights_sum, "weights_sum")),
+             L.ptr(L.dev_f32(depth, "depth")), L.ptr(L.dev_f32(image, "image")), L.ptr(L.dev_f32(normal, "normal")))
+
+
+def compact_alive_ctl(ctl, rays_alive_in, rays_alive_out, N, align=128, max_steps=1024):
+    """rays_alive_out[:n'] = the entries >= 0 of rays_alive_in[:n_alive] (order kept); ctl advanced to the next round."""
+    L.launch("mi3d_compact_alive_ctl", ctl, L.ptr(ctl), L.ptr(L.dev_typed(rays_alive_in, "rays_alive_in", torch.int32)),
+             L.ptr(L.dev_typed(rays_alive_out, "rays_alive_out", torch.int32)), int(N), int(max(align, 0)),
+             int(max_steps))

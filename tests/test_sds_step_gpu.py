@@ -119,3 +119,33 @@ def test_fp16_step_updates_parameters_and_stays_finite(cuda):
     assert torch.isfinite(model.encoder.params).all()
     assert float((model.encoder.params - before).abs().max()) > 0
     assert float((model.sigma_net.net[0].weight - w0).abs().max()) > 0
+
+
+def test_fused_adan_kernel_matches_the_torch_op_sequence(cuda):
+    """csrc/optim.hip (one kernel per tensor, clip factor on device) against the same update through torch ops - the
+    path tests/test_optim_cpu.py pins on a trajectory of the reference's own optimizer.py - over 5 steps, odd sizes,
+    with the global-norm clip active and inactive."""
+    from mi3d import optim
+    torch.manual_seed(0)
+    shapes = [(1000003,), (64, 32), (7,), (4, 64)]
+    for scale in (1e-3, 50.0):   # small gradients: clip factor 1; large: clipping
+        ref_p = [torch.randn(s, device=cuda) for s in shapes]
+        fus_p = [p.clone() for p in ref_p]
+        for q in ref_p + fus_p:
+            q.requires_grad_(True)
+        groups = lambda ps: [{"params": ps[:1], "lr": 5e-2}, {"params": ps[1:], "lr": 5e-3}]
+        a = optim.Adan(groups(ref_p), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+        b = optim.Adan(groups(fus_p), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+        a._fused_ok = lambda: False   # force the torch-op path
+        for it in range(5):
+            gs = [torch.randn(s, device=cuda) * scale for s in shapes]
+            for p, q, g in zip(ref_p, fus_p, gs):
+                p.grad, q.grad = g.clone(), g.clone()
+            a.step()
+            b.step()
+            for p, q in zip(ref_p, fus_p):
+                assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (scale, it, float((p - q).abs().max()))
+                assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=0)   # the clipped gradient, left in place
+        for p, q in zip(ref_p, fus_p):
+            for k in ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad"):
+                assert torch.allclose(a.state[p][k], b.state[q][k], rtol=5e-6, atol=1e-9), k
