@@ -259,6 +259,28 @@ int mi3d_adan_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
                    float bias_correction2, float bias_correction3_sqrt, float lr, float weight_decay, float eps,
                    int no_prox, void *stream);
 
+/* ------------------------------------------------------------------ Part 7: refine-stage point renderer */
+
+/* The two pytorch3d calls of the reference's `render_point` (nerf/refine_utils.py:306-333).
+ * mi3d_points_rasterize = pytorch3d.renderer.points.rasterize_points on ONE point cloud: points_ndc [P,3] = (x, y in
+ * pytorch3d NDC: +X left, +Y up; z = depth, points with z < 0 are skipped), image H x W, `radius` in NDC units,
+ * K = points_per_pixel <= 8.  Outputs [H,W,K]: idx (point index, -1 = unused), zbuf (may be NULL), dists (squared NDC
+ * distance to the pixel centre, -1 = unused), the K nearest covering points in ascending z (ties: lower index first).
+ * `workspace` holds the per-tile point lists (mi3d_points_rasterize_workspace bytes cover the worst case).
+ * mi3d_points_composite_forward = alphas = 1 - sqrt(clamp(0.1 dists / radius^2, 1e-3, 1)) (refine_utils.py:321-326)
+ * followed by compositing.alpha_composite: out [C,H,W] from features [P,C] (C <= 32), front to back.
+ * mi3d_points_composite_backward ACCUMULATES d out / d features into grad_features [P,C] (caller zeroes it); the point
+ * positions carry no gradient on this path (the reference optimises colours and features, nerf/utils.py:826-831). */
+size_t mi3d_points_rasterize_workspace(uint32_t P, uint32_t H, uint32_t W, float radius);
+int mi3d_points_rasterize(const float *points_ndc, uint32_t P, uint32_t H, uint32_t W, float radius,
+                          uint32_t points_per_pixel, void *workspace, size_t workspace_bytes, int32_t *idx, float *zbuf,
+                          float *dists, void *stream);
+int mi3d_points_composite_forward(const int32_t *idx, const float *dists, uint32_t H, uint32_t W, uint32_t points_per_pixel,
+                                  const float *features, uint32_t C, double radius, float *out, void *stream);
+int mi3d_points_composite_backward(const int32_t *idx, const float *dists, uint32_t H, uint32_t W,
+                                   uint32_t points_per_pixel, const float *grad_out, uint32_t C, double radius,
+                                   float *grad_features, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

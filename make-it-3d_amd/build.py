@@ -20,6 +20,7 @@ UNITS = [
     ("hashgrid.hip", []),
     ("field.hip", []),
     ("optim.hip", ["-ffp-contract=off"]),
+    ("raster.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["mi3d_common.h", "mi3d_grid.h", os.path.join("..", "..", "include", "mi3d.h")]
 

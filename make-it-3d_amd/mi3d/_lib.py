@@ -55,6 +55,10 @@ _SIGNATURES = {
     "mi3d_sumsq_accumulate": [vp, C.c_size_t, vp, vp],
     "mi3d_adan_step": [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, f32, f32, i32, f32, f32, f32, f32, f32, f32, f32, f32, f32,
                        i32, vp],
+    # Part 7 ------------------------------------------------------------------------------------------
+    "mi3d_points_rasterize": [vp, u32, u32, u32, f32, u32, vp, C.c_size_t, vp, vp, vp, vp],
+    "mi3d_points_composite_forward": [vp, vp, u32, u32, u32, vp, u32, C.c_double, vp, vp],
+    "mi3d_points_composite_backward": [vp, vp, u32, u32, u32, vp, u32, C.c_double, vp, vp],
 }
 
 
@@ -80,6 +84,8 @@ def lib():
         _lib.mi3d_hashgrid_levels.argtypes = [u32, u32, f32, u32, vp, vp, vp]
         _lib.mi3d_grid_scatter_binned_workspace.restype = C.c_size_t
         _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, f32, f32, u32, u32, f32, u32, i32]
+        _lib.mi3d_points_rasterize_workspace.restype = C.c_size_t
+        _lib.mi3d_points_rasterize_workspace.argtypes = [u32, u32, u32, f32]
     return _lib
 
 

@@ -33,7 +33,7 @@ def test_python_binding_covers_the_abi():
     lib = _lib.lib()
     declared = set(_declared())
     bound = set(_lib._SIGNATURES) | {"mi3d_abi_version", "mi3d_last_error_string", "mi3d_hashgrid_levels",
-                                     "mi3d_grid_scatter_binned_workspace"}
+                                     "mi3d_grid_scatter_binned_workspace", "mi3d_points_rasterize_workspace"}
     bound |= set(getattr(_lib, "_LATE_SIGNATURES", {}))
     assert declared <= bound, declared - bound
     for n in bound:

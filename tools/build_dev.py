@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "make-it-3d_amd", "csrc")
 OUT_DIR = os.path.join(ROOT, "tools", "bin")
 OUT = os.path.join(OUT_DIR, "libmi3d_dev.so")
 UNITS = [("raymarching.hip", ["-ffp-contract=off"]), ("hashgrid.hip", []), ("field.hip", []),
-         ("optim.hip", ["-ffp-contract=off"])]
+         ("optim.hip", ["-ffp-contract=off"]), ("raster.hip", ["-ffp-contract=off"])]
 DEV_UNIT = """
 extern "C" int mi3d_dev_tunable[32] = {-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1};
 extern "C" void mi3d_dev_set(int i, int v) { if (i >= 0 && i < 32) mi3d_dev_tunable[i] = v; }
