@@ -105,7 +105,7 @@ def test_config5_size_properties(cuda):
     radius = 2.0 / H * 2.0
     idx, zbuf, dists = refine.rasterize_points(proj, (H, W), radius, K)
     used = idx >= 0
-    assert 0.05 < float(used[..., 0].float().mean()) < 0.9
+    assert float(used[..., 0].float().mean()) > 0.05
     assert bool((used[..., 1:] <= used[..., :-1]).all())                       # used slots form a prefix
     z = torch.where(used, zbuf, torch.full_like(zbuf, float("inf")))
     later = (z[..., 1:] > z[..., :-1]) | ((z[..., 1:] == z[..., :-1]) & ((idx[..., 1:] > idx[..., :-1]) | ~used[..., 1:]))
