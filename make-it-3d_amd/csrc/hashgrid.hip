@@ -510,6 +510,18 @@ struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index
     float g0, g1;
 };
+// One record for the TWO x-neighbours of a (y, z) corner pair on a fine level.  The four values of such a pair have rank
+// one - (1 - fx) (a, b) for the corner at x, fx (a, b) for the one at x + 1, with (a, b) = w_y w_z (dfeature0, dfeature1)
+// - and the two entries differ in their low bits only (hashed: e1 = e0 ^ (2^t - 1), t = 1 + trailing ones of cx, because x
+// enters the hash with prime 1; dense: e1 = e0 + 1), so 16 bytes carry what two 12-byte records did: half the
+// lane-stores of the emit (its bound: one scattered lane-store per clock per CU) and two thirds of the bytes.
+// hdr = e0 | t << 19 (t = 0: dense "+1").  fx == 0 marks a single (only e0 receives (a, b)): pairs that straddle a bin.
+struct __attribute__((aligned(16))) RowRecord {
+    uint32_t hdr;
+    float a, b, fx;
+};
+constexpr uint32_t kRowEntryBits = 19;
+
 struct __attribute__((aligned(8))) BinRecord16 {
     uint32_t entry;
     uint32_t g;  // binary16 pair (g0 | g1 << 16), pre-scaled by the level's power of two
@@ -530,6 +542,7 @@ struct BinPlan {
     uint32_t level_max0[MI3D_MAX_LEVELS];   // first entry of the level in level_max[]; inside: [wave]
     uint64_t total_bytes;
     uint32_t half_mask;                     // levels stored as 8-byte {entry, half2} records through the staged emit
+    uint32_t row_mask;                      // fine fp32 levels stored as 16-byte x-pair records (RowRecord)
     uint32_t total_counts, total_max;
     uint32_t n_levels, n_bins;
 };
@@ -573,12 +586,17 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         // fine levels of at most 64 bins can go as 8-byte records through the line-staged emit
         const bool half = half_records && !merged && bins <= 64;
         if (half) { p.half_mask |= 1u << l; p.level_cap[l] = (p.level_cap[l] + 15u) / 16u * 16u; }
+        // fine fp32 levels whose x-neighbour entries are derivable from each other: one 16-byte record per corner pair
+        const bool row = !half && !merged && L.size <= (1u << kRowEntryBits) &&
+                         (!L.hashed || (L.size & (L.size - 1u)) == 0u);
+        if (row) { p.row_mask |= 1u << l; p.level_cap[l] = p.level_cap[l] / 2u + 64u; }
         p.level_bin0[l] = p.n_bins;
         p.level_base[l] = p.total_bytes;
         p.level_cnt0[l] = p.total_counts;
         p.level_max0[l] = p.total_max;
         p.n_bins += bins;
-        p.total_bytes += (uint64_t)p.level_waves[l] * bins * p.level_cap[l] * (half ? sizeof(BinRecord16) : sizeof(BinRecord));
+        p.total_bytes += (uint64_t)p.level_waves[l] * bins * p.level_cap[l] *
+                         (half ? sizeof(BinRecord16) : row ? sizeof(RowRecord) : sizeof(BinRecord));
         p.total_bytes = (p.total_bytes + 255u) / 256u * 256u;
         p.total_counts += p.level_waves[l] * bins;
         p.total_max += p.level_waves[l];
@@ -607,6 +625,42 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
         unsafeAtomicAdd(dst, g0);
         unsafeAtomicAdd(dst + 1, g1);
     }
+}
+
+// the x-pair of one (y, z) corner of one point as ONE RowRecord (see the struct); e0 / e1: entries of the x and x + 1 corner
+__device__ __forceinline__ void emit_row(const BinPlan &plan, const GridLevel &L, uint32_t l, uint32_t gw, uint32_t e0,
+                                         uint32_t e1, uint32_t t, float a, float b, float fx, uint32_t *fill,
+                                         char *__restrict__ arena, float *__restrict__ grad_table, float &lmax) {
+    const float gx = 1.0f - fx;
+    const bool finite = fabsf(a) <= 3.4028234663852886e38f && fabsf(b) <= 3.4028234663852886e38f;
+    lmax = finite ? fmaxf(lmax, fmaxf(fabsf(a), fabsf(b))) : __builtin_inff();  // |contribution| <= max(|a|, |b|)
+    const uint32_t cap = plan.level_cap[l], bins = level_bins(L);
+    RowRecord *base = reinterpret_cast<RowRecord *>(arena + plan.level_base[l]);
+    auto append = [&](uint32_t e, uint32_t tt, float va, float vb, float vfx) {
+        const uint32_t bin = e >> kBinShift;
+        const uint32_t slot = atomicAdd(&fill[plan.level_bin0[l] + bin], 1u);  // wave-private LDS counter
+        if (slot < cap) {
+            base[((size_t)gw * bins + bin) * cap + slot] = RowRecord{e | (tt << kRowEntryBits), va, vb, vfx};
+            return true;
+        }
+        return false;
+    };
+    if ((e0 >> kBinShift) == (e1 >> kBinShift)) {
+        if (append(e0, t, a, b, fx)) return;
+    } else {  // the pair straddles two bins: two singles (fx = 0: only the header's entry receives (a, b))
+        const bool ok0 = append(e0, 0u, gx * a, gx * b, 0.f), ok1 = append(e1, 0u, fx * a, fx * b, 0.f);
+        if (ok0 && ok1) return;
+        if (ok0 || ok1) {  // one of them went to its region: the other straight to the table
+            float *dst = grad_table + ((size_t)L.offset + (ok0 ? e1 : e0)) * 2;
+            const float w = ok0 ? fx : gx;
+            unsafeAtomicAdd(dst, w * a); unsafeAtomicAdd(dst + 1, w * b);
+            return;
+        }
+    }
+    // region full: straight to the table
+    float *d0 = grad_table + ((size_t)L.offset + e0) * 2, *d1 = grad_table + ((size_t)L.offset + e1) * 2;
+    unsafeAtomicAdd(d0, gx * a); unsafeAtomicAdd(d0 + 1, gx * b);
+    unsafeAtomicAdd(d1, fx * a); unsafeAtomicAdd(d1 + 1, fx * b);
 }
 
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
@@ -673,9 +727,24 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
                 const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                if (!merge) {  // fine level: every point is its own run, the lane emits its 8 corners
-                    // (appending the two x-neighbours of a corner pair together - one counter update, 24 contiguous
-                    // bytes - was measured: 106 -> 114 ms per 141 M evaluations, the store path is paid per lane-store)
+                if (!merge && ((plan.row_mask >> l) & 1u)) {  // fine level, one 16-byte record per x-corner pair
+                    if (has) {
+                        // t: e1 = e0 ^ (2^t - 1) on a hashed level (the bits a +1 carry flips in cx), 0 = dense "+1"
+                        const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~cx) + 1u : 0u;
+                        const float wyz[4] = {gy * gz, fy * gz, gy * fz, fy * fz};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const uint32_t e0 = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
+                            const uint32_t e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
+                            emit_row(plan, L, l, gw, e0, e1, t, wyz[j] * d.x, wyz[j] * d.y, fx, fill,
+                                     reinterpret_cast<char *>(arena), grad_table, lmax);
+                        }
+                    }
+                    continue;
+                }
+                if (!merge) {  // fine level without the pair structure: every point emits its 8 corners
+                    // (appending the two 12-byte records of an x-pair together - one counter update, 24 contiguous
+                    // bytes - was measured: 106 -> 114 ms per 141 M evaluations; the store path is paid per lane-store)
                     if (has) {
 #pragma unroll
                         for (uint32_t k = 0; k < 8; ++k) {
@@ -950,7 +1019,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     const uint32_t cap = plan.level_cap[lvl], n_waves = plan.level_waves[lvl], bins = level_bins(T.level[lvl]);
     const uint32_t lb = b - plan.level_bin0[lvl];
     for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) acc[i] = 0ull;
-    const bool half = (plan.half_mask >> lvl) & 1u;
+    const bool half = (plan.half_mask >> lvl) & 1u, row = (plan.row_mask >> lvl) & 1u;
     float scale;
     double unscale;
     if (half) {
@@ -1002,6 +1071,35 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                         const float g1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec[u].y >> 16));
                         atomicAdd(&acc[local], (unsigned long long)(long long)(g0 * scale));
                         atomicAdd(&acc[local + 1], (unsigned long long)(long long)(g1 * scale));
+                    }
+                }
+            }
+        } else if (row) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
+            const GridLevel &L = T.level[lvl];
+            for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
+                uint4 rec[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    const uint32_t i = i0 + u * kWave + lane;
+                    rec[u] = i < cnt ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    if (i0 + u * kWave + lane < cnt) {
+                        const uint32_t e0 = rec[u].x & ((1u << kRowEntryBits) - 1u), t = rec[u].x >> kRowEntryBits;
+                        const float a = __uint_as_float(rec[u].y), bb = __uint_as_float(rec[u].z),
+                                    fx = __uint_as_float(rec[u].w);
+                        const float gx = 1.0f - fx;
+                        const uint32_t l0 = (e0 & (kBinEntries - 1)) * 2;
+                        atomicAdd(&acc[l0], (unsigned long long)__float2ll_rn((gx * a) * scale));
+                        atomicAdd(&acc[l0 + 1], (unsigned long long)__float2ll_rn((gx * bb) * scale));
+                        if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
+                            const uint32_t e1 = L.hashed ? (e0 ^ (((1u << t) - 1u) & (L.size - 1u))) : e0 + 1u;
+                            const uint32_t l1 = (e1 & (kBinEntries - 1)) * 2;
+                            atomicAdd(&acc[l1], (unsigned long long)__float2ll_rn((fx * a) * scale));
+                            atomicAdd(&acc[l1 + 1], (unsigned long long)__float2ll_rn((fx * bb) * scale));
+                        }
                     }
                 }
             }
