@@ -495,8 +495,9 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         of its BIN (8192 consecutive entries of one level = 64 KB of gradient).  One private
 //                         region per (wave, bin): an append is a wave-private LDS counter and a plain store.  The
 //                         arena is wave-major so the regions a wave is filling at any moment (one level's bins) sit
-//                         in a few MB: a handful of TLB pages, and with 2048 emitting waves the lines being
-//                         appended to fit the L2s (measured: 8192 waves 40 ms, 2048 waves 28 ms per 5.4 M samples).
+//                         in a few MB: a handful of TLB pages, and with ~1000 emitting waves the lines being
+//                         appended to fit the L2s (round 2, 16-byte pair records, 141 M evaluations: 256 waves 175 ms,
+//                         512: 110, 768: 89, 1024: 79, 1536: 80, 2048: 86, 4096: 94).
 //                         On levels whose cells are longer than a marching step, equal-cell RUNS of consecutive
 //                         lanes are summed first (through an LDS slab, see k_scatter_runs) and emit one record set.
 //   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS in
@@ -504,7 +505,7 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
-constexpr uint32_t kEmitWavesMax = 2048, kReduceSplit = 4;
+constexpr uint32_t kEmitWavesMax = 1024, kReduceSplit = 4;
 
 struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index

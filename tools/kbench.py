@@ -136,7 +136,7 @@ def main():
         g1 = g[:, :n].contiguous()
         res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
-        for fw in (1024, 4096):
+        for fw in (256, 512, 768, 1024, 1536):
             tune(T_EMIT_FINE, fw)
             res[f"scatter_fp32_P13_fine_waves{fw}_ms"] = timeit(lambda: field_ops.scatter_binned(
                 xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
