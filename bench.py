@@ -16,9 +16,10 @@ RCCL all-reduce per step; `value` counts view-steps of all ranks per second (wea
 
 The HEADLINE (`value`, `ms_per_step`) is the like-for-like configuration: what the reference's main.py gets with the
 drop-in packages and NO edits to nerf/sd.py / nerf/utils.py - the reference's two-backward SDS schedule
-(`latents.backward(retain_graph=True)` then `scaler.scale(loss).backward()`) - and fp32 gradient records in the
-hash-grid scatter (tiny-cuda-nn adds fp32 products).  `variants` reports the other three corners of
-{records: fp32 | half} x {sds_backward: reference | single}, each timed on its own steps.
+(`latents.backward(retain_graph=True)` then `scaler.scale(loss).backward()`) - and fp32 gradient contributions in the
+hash-grid scatter (tiny-cuda-nn adds fp32 products; the binary16-record mode of round 1 is gone: the 16-byte fp32
+pair records of round 2 are faster than it was).  `variants_ms_per_step` adds the hand-merged single-backward schedule
+(needs edits to nerf/sd.py), timed on its own steps.
 
 The JSON line also carries
   roofline     : the step's dominant kernel - algorithmic bytes per launch (1024 B per field evaluation
@@ -250,7 +251,7 @@ def main():
         return bench_refine(args, wl, dev, rank, world)
     views = wl["views"]
 
-    from mi3d import dp, field_ops, grid_ops, rays as R, sd_standin, sds_step
+    from mi3d import dp, grid_ops, rays as R, sd_standin, sds_step
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
     # GradScaler: the reference constructs it at 65536 (nerf/utils.py:309).  On this workload the normal-smoothness
     # regulariser back-propagates through safe_normalize of finite differences that fp16 rounds to exactly zero
@@ -305,7 +306,6 @@ def main():
     optimizer.step = timed("optimizer", _opt_step)
 
     def run(records, schedule, steps, warmup):
-        field_ops.HALF_RECORDS = records == "half"
         step = make_step(model, optimizer, scaler, schedule, bucket.all_reduce_mean)
         for _ in range(warmup):
             step()
@@ -336,12 +336,8 @@ def main():
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step")
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
     if args.variant_steps > 0 and not render_only:
-        for rec in ("fp32", "half"):
-            for sch in ("reference", "single"):
-                if (rec, sch) != HEADLINE:
-                    e, _ = run(rec, sch, args.variant_steps, 1)
-                    variants[f"records={rec},sds_backward={sch}"] = 1e3 * e / args.variant_steps
-    field_ops.HALF_RECORDS = False
+        e, _ = run("fp32", "single", args.variant_steps, 1)
+        variants["records=fp32,sds_backward=single"] = 1e3 * e / args.variant_steps
 
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
     line = None
@@ -368,10 +364,9 @@ def main():
                  "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
                  "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
                  "k_grid_encode_planes"),
-            roof("grid gradient scatter = k_bin_emit (+ k_bin_emit16 with half records) + k_bin_reduce per slice "
-                 "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
+            roof("grid gradient scatter = k_bin_emit + k_bin_reduce per slice (records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
                  "GB/s", "algorithmic bytes = 2048 B per evaluation read-modify-write of the table; the binned path "
-                 "moves 8 records x 12 B per (evaluation, level) out and back instead; one call per NeRF backward: the "
+                 "moves 4 x-pair records x 16 B per (evaluation, fine level) out and back instead; one call per NeRF backward: the "
                  "SDS pass reaches stencil point 0 only (1/13 of the evaluations), the regulariser pass all 13",
                  "scatter_binned"),
             roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
@@ -388,9 +383,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 hash grid (fp32 gather, fp32 12-byte gradient records) + f16 MFMA MLP (torch.autocast "
-                     "semantics), f16 U-Net; variants with 'records=half' round each fine-level (8-15) gradient "
-                     "contribution to binary16",
+            "dtype": "f32 hash grid (fp32 gather, fp32 gradient contributions accumulated in 64-bit fixed point) + f16 "
+                     "MFMA MLP (torch.autocast semantics), f16 U-Net",
             "data": "synthetic (reference orbit rays, random-init weights, analytic occupancy)",
             "config": {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
                                    f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step (t={T_FIXED}: the SDS "

@@ -172,25 +172,21 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
                              uint32_t log2_hashmap_size, float step, float *grad_params, void *stream);
 
 /* The same scatter without global atomics: every corner contribution (equal-cell runs of neighbouring samples
- * summed first on the coarse levels) is appended as a 12-byte record to the region of its 64-KB gradient bin, then
- * each bin is accumulated in LDS and added to the table (see hashgrid.hip).
+ * summed first on the coarse levels; the two x-neighbours of a corner pair as ONE 16-byte record on the fine levels)
+ * is appended to the region of its 64-KB gradient bin, then each bin is accumulated in LDS in 64-bit fixed point and
+ * added to the table (see hashgrid.hip).  fp32 contributions throughout; a level that receives a non-finite
+ * contribution is filled with NaN (what the float atomics of the reference would have left in the table).
  * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
  * dx_plane_rows = P*n).
  * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
  * it; with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
- * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice.
- * `level_absmax` (device float[16], may be NULL): the largest |dout| of every level, as mi3d_mlp_backward writes it.
- * When given, the fine levels use 8-byte {entry, binary16 pair} records scaled by an exact power of two below it and
- * leave through line-sized LDS stages - the precision torch.autocast gives these gradients anyway; NULL keeps every
- * record fp32 (and `half_records` of the workspace query must be 0). */
+ * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice. */
 size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
-                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
-                                          int half_records);
+                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size);
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                              uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
-                             const float *level_absmax, void *workspace, size_t workspace_bytes, float *grad_params,
-                             void *stream);
+                             void *workspace, size_t workspace_bytes, float *grad_params, void *stream);
 
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 
@@ -210,15 +206,11 @@ int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const fl
 /* Backward of the above for upstream gradient dout [n, dim_out]: writes dx and ACCUMULATES the weight and bias
  * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
  * dx_plane_rows == 0: dx is [n, dim_in] rows; otherwise dx is level-major planes [dim_in/2][dx_plane_rows][2]
- * (feature pair (2l, 2l+1) of row r at dx[(l*dx_plane_rows + r)*2]), the layout mi3d_grid_scatter_binned consumes,
- * and `level_absmax` (device float[dim_in/2], zeroed by the caller, may be NULL) receives max |dx| per level - +inf
- * as soon as a level holds a non-finite value (the binned scatter then poisons that level with NaN, as the float
- * atomics of the reference would). */
+ * (feature pair (2l, 2l+1) of row r at dx[(l*dx_plane_rows + r)*2]), the layout mi3d_grid_scatter_binned consumes. */
 int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1,
                       const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
                       uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx,
-                      uint32_t dx_plane_rows,
-                      float *level_absmax, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
+                      uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream);
 
 /* ------------------------------------------------------------------ Part 5: the field head */

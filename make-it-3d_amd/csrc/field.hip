@@ -306,13 +306,6 @@ template <class P> __device__ __forceinline__ typename P::KB dout_kb(const f32x4
     return k;
 }
 
-// max(m, |a|, |b|), or +inf as soon as a or b is not finite: the per-level maxima double as the overflow signal of
-// the binned scatter (fmaxf alone would drop a NaN)
-__device__ __forceinline__ float absmax_or_inf(float m, float a, float b) {
-    const bool finite = fabsf(a) <= 3.4028234663852886e38f && fabsf(b) <= 3.4028234663852886e38f;
-    return finite ? fmaxf(m, fmaxf(fabsf(a), fabsf(b))) : __builtin_inff();
-}
-
 __device__ __forceinline__ f32x16 splat(float v) {
     f32x16 a;
 #pragma unroll
@@ -391,8 +384,7 @@ template <class P, int U, int WPS>
 __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
                                                                            const float *__restrict__ dout, uint32_t n,
                                                                            Weights w, float *__restrict__ dx,
-                                                                           uint32_t dx_planes,
-                                                                           float *__restrict__ level_absmax, Grads g) {
+                                                                           uint32_t dx_planes, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_ALL_COUNT);
@@ -418,10 +410,6 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 #pragma unroll
         for (int b = 0; b < NTH; ++b) gW2[a][b] = splat(0.f);
     }
-
-    float lvmax[8];  // planes mode: largest |dx| per level this lane wrote (levels 4c + 2h + u at index 2c + u)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lvmax[j] = 0.f;
 
     // the rows of the NEXT group of tiles are requested before the current group's products start and are consumed one
     // iteration later; tile u of a group is `u * n_waves` tiles further on, so every wave instruction still reads 32
@@ -567,8 +555,6 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         f32x2 a = {acc[u][4 * c], acc[u][4 * c + 1]}, b = {acc[u][4 * c + 2], acc[u][4 * c + 3]};
-                        lvmax[2 * c] = absmax_or_inf(lvmax[2 * c], a[0], a[1]);
-                        lvmax[2 * c + 1] = absmax_or_inf(lvmax[2 * c + 1], b[0], b[1]);
                         const size_t lvl = 4 * c + 2 * h;
                         __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + (lvl * dx_planes + row[u]) * 2));
                         __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((lvl + 1) * dx_planes + row[u]) * 2));
@@ -719,18 +705,6 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
         }
     }
 
-    // ---- per-level |dx| maxima (the binned scatter's 8-byte records are scaled by them): lanes of one half hold the
-    // same eight levels; non-negative floats order like their bit patterns
-    if (dx_planes && level_absmax != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float m = lvmax[j];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            if (p == 0 && m > 0.f)
-                atomicMax(reinterpret_cast<unsigned int *>(level_absmax) + 4 * (j >> 1) + 2 * h + (j & 1), __float_as_uint(m));
-        }
-    }
     // ---- reduce the weight gradients across the workgroup in LDS, then one atomic per element per workgroup
     __syncthreads();
     float *red = reinterpret_cast<float *>(lds);
@@ -944,8 +918,7 @@ int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const fl
 
 int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, uint32_t dx_plane_rows,
-                      float *level_absmax, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream) {
     if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
         (dx_plane_rows != 0 && dx_plane_rows < n))
@@ -959,21 +932,21 @@ int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, 
     const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
     if (half_mode && variant == 1) {  // one tile at a time
         hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, level_absmax, g);
+                           n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
     if (half_mode && variant == 2) {  // one tile at a time, two waves per SIMD (256 registers, spills)
         hipLaunchKernelGGL((k_mlp_backward<F16, 1, 2>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, level_absmax, g);
+                           n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
 #endif
     if (half_mode)
         hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, level_absmax, g);
+                           n, w, dx, dx_plane_rows, g);
     else
         hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, level_absmax, g);
+                           n, w, dx, dx_plane_rows, g);
     return (int)hipGetLastError();
 }
 

@@ -523,17 +523,6 @@ struct __attribute__((aligned(16))) RowRecord {
 };
 constexpr uint32_t kRowEntryBits = 19;
 
-struct __attribute__((aligned(8))) BinRecord16 {
-    uint32_t entry;
-    uint32_t g;  // binary16 pair (g0 | g1 << 16), pre-scaled by the level's power of two
-};
-#ifndef MI3D_EMIT16_CHUNK
-#define MI3D_EMIT16_CHUNK 16
-#endif
-// records per staged flush (16 x 8 B = one 128-byte line) and ring per bin (two chunks)
-constexpr uint32_t kChunk = MI3D_EMIT16_CHUNK, kRing = 2 * kChunk, kChunkLanes = kChunk / 2;
-constexpr size_t kEmit16LdsBytes = (size_t)4 * 64 * kRing * 8 + (size_t)4 * 256 * 4;  // kWaves = 4
-
 struct BinPlan {
     uint32_t level_bin0[MI3D_MAX_LEVELS];   // first bin of each level (bins are numbered level by level)
     uint32_t level_cap[MI3D_MAX_LEVELS];    // records one (wave, bin) region of that level holds
@@ -542,7 +531,6 @@ struct BinPlan {
     uint32_t level_cnt0[MI3D_MAX_LEVELS];   // first entry of the level in counts[]; inside: [wave][bin]
     uint32_t level_max0[MI3D_MAX_LEVELS];   // first entry of the level in level_max[]; inside: [wave]
     uint64_t total_bytes;
-    uint32_t half_mask;                     // levels stored as 8-byte {entry, half2} records through the staged emit
     uint32_t row_mask;                      // fine fp32 levels stored as 16-byte x-pair records (RowRecord)
     uint32_t total_counts, total_max;
     uint32_t n_levels, n_bins;
@@ -556,14 +544,13 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
     return nw ? nw : kWaves;
 }
 
-// The plan for slices of n_slice samples.  Fine levels are emitted by at most 2048 waves (the lines being appended to
+// The plan for slices of n_slice samples.  Fine levels are emitted by at most 1024 waves (the lines being appended to
 // must fit the L2s); the coarse levels' run merging is latency-bound and emits few records, so it gets up to 16384.
 // Region capacities - hashed levels: the uniform share of the UNMERGED record count plus 25 % (the hash spreads them
 // evenly).  Dense levels: bins are spatial, a wave's samples cluster in few of them, and merging thins the records by
 // an unknown factor: the share assumes a quarter of the geometric run length and two-fold imbalance.  A full region is
 // not an error - the overflow goes to the table by atomics.
-inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels,
-                        bool half_records) {
+inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels) {
     const uint32_t fine_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_FINE_WAVES, kEmitWavesMax);
     const uint32_t coarse_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_COARSE_WAVES, 16384);
     BinPlan p{};
@@ -584,11 +571,8 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
             per = per / run * 2.0;
         }
         p.level_cap[l] = (uint32_t)per + 64u;
-        // fine levels of at most 64 bins can go as 8-byte records through the line-staged emit
-        const bool half = half_records && !merged && bins <= 64;
-        if (half) { p.half_mask |= 1u << l; p.level_cap[l] = (p.level_cap[l] + 15u) / 16u * 16u; }
         // fine fp32 levels whose x-neighbour entries are derivable from each other: one 16-byte record per corner pair
-        const bool row = !half && !merged && L.size <= (1u << kRowEntryBits) &&
+        const bool row = !merged && L.size <= (1u << kRowEntryBits) &&
                          (!L.hashed || (L.size & (L.size - 1u)) == 0u);
         if (row) { p.row_mask |= 1u << l; p.level_cap[l] = p.level_cap[l] / 2u + 64u; }
         p.level_bin0[l] = p.n_bins;
@@ -597,7 +581,7 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         p.level_max0[l] = p.total_max;
         p.n_bins += bins;
         p.total_bytes += (uint64_t)p.level_waves[l] * bins * p.level_cap[l] *
-                         (half ? sizeof(BinRecord16) : row ? sizeof(RowRecord) : sizeof(BinRecord));
+                         (row ? sizeof(RowRecord) : sizeof(BinRecord));
         p.total_bytes = (p.total_bytes + 255u) / 256u * 256u;
         p.total_counts += p.level_waves[l] * bins;
         p.total_max += p.level_waves[l];
@@ -808,187 +792,6 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
         level_max[plan.level_max0[lane] + gw] = lmax_all[wave_in_wg][lane];
 }
 
-// ---------------------------------------------------------------- pass 1 for the fine levels, 8-byte records
-// PMC on the kernel above: WRITE_SIZE is 2x the record bytes - a 12-byte append is a partial-line write and the lines
-// leave the L2 before their neighbours arrive.  Under torch.autocast the upstream gradient is binary16 anyway, so here a
-// record is {entry, half2}: values are scaled by an exact power of two taken from the level's largest |feature
-// gradient| (level_absmax, written by the MLP backward) so that they sit below 2^15, and records are STAGED per bin in
-// LDS (a ring of 32) and leave 16 at a time - one full 128-byte line per store group, eight lanes per line.
-// Loop order is level-major (a wave runs all its tiles for one level, then the next) so the 64 rings are the only
-// open streams.  Slots are ranked per instruction with an LDS counter, so any number of lanes may hit one bin: those
-// beyond the ring window wait for the flush that frees it.
-__device__ __forceinline__ float level_scale_exp(const float *level_absmax, uint32_t l, int &k) {
-    const float m = level_absmax[l];
-    int e = 0;
-    (void)frexpf(m, &e);  // m < 2^e
-    k = 15 - e;
-    k = k > 126 ? 126 : (k < -126 ? -126 : k);
-    return m;
-}
-
-__global__ __launch_bounds__(kWave *kWaves) void k_bin_emit16(PointSet ps, uint32_t s_begin, uint32_t s_end,
-                                                               const float *__restrict__ dplanes, uint32_t plane_rows,
-                                                               uint32_t n_rows,
-                                                               GridTable T, BinPlan plan, uint32_t level_mask,
-                                                               uint32_t n_waves, const float *__restrict__ level_absmax,
-                                                               char *__restrict__ arena, uint32_t *__restrict__ counts,
-                                                               float *__restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) uint2 emit16_lds[];  // kEmit16LdsBytes: rings, then 4 u32[64] per wave
-    const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
-    if (gw >= n_waves) return;
-    uint2 *stage = emit16_lds + (size_t)wave_in_wg * 64 * kRing;
-    uint32_t *small = reinterpret_cast<uint32_t *>(emit16_lds + (size_t)kWaves * 64 * kRing) + wave_in_wg * 256;
-    uint32_t *cnt = small, *fl = small + 64, *tmp = small + 128, *list = small + 192;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-
-    for (uint32_t l = 0; l < T.n_levels; ++l) {
-        if (!((level_mask >> l) & 1u)) continue;
-        const GridLevel L = T.level[l];
-        const uint32_t bins = level_bins(L), cap = plan.level_cap[l];
-        BinRecord16 *rbase = reinterpret_cast<BinRecord16 *>(arena + plan.level_base[l]) + (size_t)gw * bins * cap;
-        uint32_t *cnt_out = counts + plan.level_cnt0[l] + (size_t)gw * bins;
-        int kexp;
-        const float amax = level_scale_exp(level_absmax, l, kexp);
-        if (!(amax > 0.f) || !(amax < 3.0e38f)) {  // nothing on this level, or non-finite values (k_bin_reduce poisons it)
-            if ((uint32_t)lane < bins) cnt_out[lane] = 0;
-            continue;
-        }
-        const float scale = ldexpf(1.0f, kexp), unscale = ldexpf(1.0f, -kexp);
-        cnt[lane] = 0; fl[lane] = 0; tmp[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-
-        // flush every complete chunk: lane b looks at bin b, eight lanes move one 128-byte chunk
-        auto flush_ready = [&]() {
-            // only slots inside the ring window AT ENTRY are known to be written (lanes beyond it are still waiting in
-            // append), so that is as far as this call may flush - however far cnt has already run ahead
-            uint32_t lim = 0;
-            if ((uint32_t)lane < bins) {
-                const uint32_t c = cnt[lane], w = fl[lane] * kChunk + kRing;
-                lim = c < w ? c : w;
-            }
-            while (true) {
-                bool rdy = false;
-                if ((uint32_t)lane < bins) rdy = lim - fl[lane] * kChunk >= kChunk;
-                const unsigned long long ready = __ballot(rdy);
-                if (ready == 0ull) break;
-                const uint32_t nr = (uint32_t)__popcll(ready);
-                if (rdy) list[__popcll(ready & lt)] = (uint32_t)lane;
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t j0 = 0; j0 < nr; j0 += kWave / kChunkLanes) {
-                    const uint32_t j = j0 + (uint32_t)lane / kChunkLanes;
-                    if (j < nr) {
-                        const uint32_t b = list[j], f = fl[b], part = (uint32_t)lane % kChunkLanes;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(&stage[b * kRing + (f & 1u) * kChunk + part * 2]);
-                        if ((f + 1) * kChunk <= cap) {
-                            *reinterpret_cast<uint4 *>(rbase + (size_t)b * cap + f * kChunk + part * 2) = v;
-                        } else {  // region full: these two records go straight to the table
-                            const uint32_t ent[2] = {v.x, v.z}, gg[2] = {v.y, v.w};
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                const float g0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(gg[t] & 0xFFFFu)) * unscale;
-                                const float g1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(gg[t] >> 16)) * unscale;
-                                float *dst = grad_table + ((size_t)L.offset + ent[t]) * 2;
-                                if (g0 != 0.f) unsafeAtomicAdd(dst, g0);
-                                if (g1 != 0.f) unsafeAtomicAdd(dst + 1, g1);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (rdy) fl[lane] += 1;
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        // the eight corner records of every active lane: slots are ranked per bin over the whole batch with an LDS
-        // counter (any number of lanes / corners may share a bin), written where they fall inside the ring window,
-        // and whoever falls beyond it waits for the flush that frees it
-        auto append8 = [&](bool active, const uint32_t (&e)[8], const uint32_t (&g)[8]) {
-            uint32_t slot[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) slot[k] = active ? atomicAdd(&tmp[e[k] >> kBinShift], 1u) : 0u;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) slot[k] += active ? cnt[e[k] >> kBinShift] : 0u;
-            __builtin_amdgcn_wave_barrier();
-            {
-                const uint32_t t = tmp[lane];
-                if (t) { cnt[lane] += t; tmp[lane] = 0; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t pend = active ? 0xFFu : 0u;
-            while (true) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t b = e[k] >> kBinShift;
-                    if (((pend >> k) & 1u) && slot[k] - fl[b] * kChunk < kRing) {
-                        stage[b * kRing + (slot[k] & (kRing - 1))] = make_uint2(e[k], g[k]);
-                        pend &= ~(1u << k);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const bool more = __any(pend != 0u);
-                flush_ready();
-                if (!more) break;
-            }
-        };
-
-        for (uint32_t s0 = s_begin + gw * kWave; s0 < s_end; s0 += n_waves * kWave) {
-            const uint32_t s = s0 + lane;
-            const bool valid = s < s_end;
-            float base[2][3];
-            load_bases(ps, s, valid, base);
-            const float2 zero2 = make_float2(0.f, 0.f);
-            // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
-            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + s;
-            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[(size_t)n_rows] : zero2,
-                   d2 = (valid && 2 < ps.P) ? prow[(size_t)2 * n_rows] : zero2;
-            for (uint32_t p = 0; p < ps.P; ++p) {
-                const float2 d = d0;
-                d0 = d1; d1 = d2;
-                d2 = (valid && p + 3 < ps.P) ? prow[(size_t)(p + 3) * n_rows] : zero2;
-                const bool has = valid && (d.x != 0.f || d.y != 0.f);
-                if (!__any(has)) continue;
-                float q[3];
-                point_of(ps, base, p, q);
-                uint32_t cx, cy, cz;
-                float fx, fy, fz;
-                grid_cell(q[0], L.scale, cx, fx);
-                grid_cell(q[1], L.scale, cy, fy);
-                grid_cell(q[2], L.scale, cz, fz);
-                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
-                const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                const float sx = d.x * scale, sy = d.y * scale;
-                uint32_t ek[8], gk[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) {
-                    ek[k] = grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2));
-                    const unsigned short h0 = __builtin_bit_cast(unsigned short, (_Float16)(wk[k] * sx));
-                    const unsigned short h1 = __builtin_bit_cast(unsigned short, (_Float16)(wk[k] * sy));
-                    gk[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                }
-                append8(has, ek, gk);
-            }
-        }
-        // end of the level: pad every bin to a whole chunk with null records, flush, publish the counts
-        if ((uint32_t)lane < bins) {
-            uint32_t c = cnt[lane];
-            const uint32_t full = (c + kChunk - 1) / kChunk * kChunk;
-            for (; c < full; ++c) stage[lane * kRing + (c & (kRing - 1))] = make_uint2(0u, 0u);
-            cnt[lane] = full;
-        }
-        __builtin_amdgcn_wave_barrier();
-        flush_ready();
-        if ((uint32_t)lane < bins) {
-            const uint32_t c = fl[lane] * kChunk;
-            cnt_out[lane] = c < cap ? c : cap / kChunk * kChunk;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 constexpr int kReduceWaves = 16;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
 
 // A level that received a non-finite gradient: every entry of the bin becomes NaN, so that torch's GradScaler (and
@@ -1003,11 +806,10 @@ __device__ __forceinline__ void poison_bin(const GridLevel &L, uint32_t lb, floa
 // Every record value is scaled by a power of two 2^k chosen from the largest |value| any wave emitted for the level
 // (|v| 2^k < 2^38, so 2^24 records cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is
 // exact; what is dropped is whatever lies more than 38 binary digits below the level's largest contribution - far
-// below what fp32 running sums (24 digits) or the reference's fp16 autocast gradients resolve.
+// below what fp32 running sums (24 digits) resolve.
 __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *__restrict__ arena,
                                                                      const uint32_t *__restrict__ counts,
-                                                                     const float *__restrict__ level_max,
-                                                                     const float *__restrict__ level_absmax, GridTable T,
+                                                                     const float *__restrict__ level_max, GridTable T,
                                                                      BinPlan plan, float *__restrict__ grad_table) {
     extern __shared__ unsigned long long acc[];  // [kBinEntries * 2]
     __shared__ float wg_max[kReduceWaves];
@@ -1020,19 +822,10 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     const uint32_t cap = plan.level_cap[lvl], n_waves = plan.level_waves[lvl], bins = level_bins(T.level[lvl]);
     const uint32_t lb = b - plan.level_bin0[lvl];
     for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) acc[i] = 0ull;
-    const bool half = (plan.half_mask >> lvl) & 1u, row = (plan.row_mask >> lvl) & 1u;
+    const bool row = (plan.row_mask >> lvl) & 1u;
     float scale;
     double unscale;
-    if (half) {
-        // records hold binary16 values pre-scaled by 2^kexp (|v| < 2^15); times 2^24 every binary16 is an exact integer
-        int kexp;
-        const float amax = level_scale_exp(level_absmax, lvl, kexp);
-        if (amax != amax || amax > 3.0e38f) { poison_bin(T.level[lvl], lb, grad_table); return; }
-        if (!(amax > 0.f)) return;
-        scale = 16777216.0f;
-        unscale = ldexp(1.0, -(24 + kexp));
-        __syncthreads();
-    } else {
+    {
         float m = 0.f;
         for (uint32_t r = threadIdx.x; r < n_waves; r += blockDim.x) m = fmaxf(m, level_max[plan.level_max0[lvl] + r]);
 #pragma unroll
@@ -1055,27 +848,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     constexpr uint32_t U = 8;  // records in flight per lane
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += kReduceSplit * kReduceWaves) {
         const uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
-        if (half) {
-            const uint2 *src = reinterpret_cast<const uint2 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
-            for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
-                uint2 rec[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = i < cnt ? src[i] : make_uint2(0u, 0u);
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    if (rec[u].y != 0u) {
-                        const uint32_t local = (rec[u].x & (kBinEntries - 1)) * 2;
-                        const float g0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec[u].y & 0xFFFFu));
-                        const float g1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec[u].y >> 16));
-                        atomicAdd(&acc[local], (unsigned long long)(long long)(g0 * scale));
-                        atomicAdd(&acc[local + 1], (unsigned long long)(long long)(g1 * scale));
-                    }
-                }
-            }
-        } else if (row) {
+        if (row) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
             const GridLevel &L = T.level[lvl];
             for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
@@ -1254,42 +1027,39 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
 }
 
 size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
-                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
-                                          int half_records) {
+                                          uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || n == 0) return 0;
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    return bin_workspace_bytes(plan_for(T, n, P, step01, default_merge_levels(T, step01 * (3.0f / 1.05f)), half_records != 0));
+    return bin_workspace_bytes(plan_for(T, n, P, step01, default_merge_levels(T, step01 * (3.0f / 1.05f))));
 }
 
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                              uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
-                             const float *level_absmax, void *workspace, size_t workspace_bytes, float *grad_params,
-                             void *stream) {
+                             void *workspace, size_t workspace_bytes, float *grad_params, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
         (P0 < P && x2 == nullptr))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     hipStream_t st = as_stream(stream);
-    const bool half_records = level_absmax != nullptr;  // 8-byte records need the per-level scale
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     // the record path run-merges only where it pays (cells at least 3 marching steps long); levels with shorter runs
-    // emit per-point records, which under half_records go through the staged 8-byte path
+    // emit per-point records (16-byte x-pair records where the level's entries allow it)
     const uint32_t merge_atomic = default_merge_levels(T, step01);
     const uint32_t merge_levels = default_merge_levels(T, step01 * (3.0f / 1.05f));
     const uint32_t plane_rows = n * P;
 
     // the slice: the largest sample count (halving from n) whose record arena fits the workspace
     uint64_t n_slice = n;
-    BinPlan plan = plan_for(T, n_slice, P, step01, merge_levels, half_records);
+    BinPlan plan = plan_for(T, n_slice, P, step01, merge_levels);
     while (n_slice > kWave && bin_workspace_bytes(plan) > workspace_bytes) {
         n_slice = (n_slice + 1) / 2;
-        plan = plan_for(T, n_slice, P, step01, merge_levels, half_records);
+        plan = plan_for(T, n_slice, P, step01, merge_levels);
     }
     if (workspace == nullptr || bin_workspace_bytes(plan) > workspace_bytes) {
         // no usable workspace: the atomic kernels, with private copies of the table against same-line serialisation
@@ -1315,28 +1085,20 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     // per call: the attribute is per device and the call is a host-side table write (no static, re-entrant)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_reduce);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_emit16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kEmit16LdsBytes);
-    // the fine levels (>= merge_levels) and the coarse ones are two roles of one emit launch; levels stored as 8-byte
-    // records go through the staged emit instead
+    // the fine levels (>= merge_levels) and the coarse ones are two roles of one emit launch
     const uint32_t all = (uint32_t)((1ull << T.n_levels) - 1);
-    const uint32_t coarse_mask = (merge_levels ? (all & ((1u << merge_levels) - 1u)) : 0u) & ~plan.half_mask;
-    const uint32_t fine_mask = all & ~coarse_mask & ~plan.half_mask;
+    const uint32_t coarse_mask = merge_levels ? (all & ((1u << merge_levels) - 1u)) : 0u;
+    const uint32_t fine_mask = all & ~coarse_mask;
     const uint32_t fine_waves = fine_mask ? plan.level_waves[__builtin_ctz(fine_mask)] : 0u;
     const uint32_t coarse_waves = coarse_mask ? plan.level_waves[__builtin_ctz(coarse_mask)] : 0u;
-    const uint32_t half_waves = plan.half_mask ? plan.level_waves[__builtin_ctz(plan.half_mask)] : 0u;
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
-        if (plan.half_mask)
-            hipLaunchKernelGGL(k_bin_emit16, dim3(half_waves / kWaves), dim3(kWave * kWaves), kEmit16LdsBytes, st, ps, (uint32_t)s0, s1,
-                               dout_planes, plane_rows, n, T, plan, plan.half_mask, half_waves, level_absmax, arena, counts,
-                               grad_params);
         if (fine_waves + coarse_waves)
             hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
                                (uint32_t)s0, s1, dout_planes, plane_rows, n, T, plan, merge_levels, fine_mask, fine_waves,
                                coarse_mask, coarse_waves, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
-                           counts, level_max, level_absmax, T, plan, grad_params);
+                           counts, level_max, T, plan, grad_params);
     }
     return (int)hipGetLastError();
 }

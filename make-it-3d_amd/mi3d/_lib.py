@@ -43,11 +43,11 @@ _SIGNATURES = {
     "mi3d_grid_encode_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, vp, vp],
     "mi3d_grid_scatter_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
     "mi3d_grid_encode_points_planes": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
-    "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp, C.c_size_t, vp, vp],
+    "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, C.c_size_t, vp, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],
     "mi3d_mlp_forward": [vp, u32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
-    "mi3d_mlp_backward": [vp, u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_mlp_backward": [vp, u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, u32, vp, vp, vp, vp, vp, vp, vp],
     # Part 5 ------------------------------------------------------------------------------------------
     "mi3d_field_head_forward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
     "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
@@ -83,7 +83,7 @@ def lib():
         _lib.mi3d_hashgrid_levels.restype = u32
         _lib.mi3d_hashgrid_levels.argtypes = [u32, u32, f32, u32, vp, vp, vp]
         _lib.mi3d_grid_scatter_binned_workspace.restype = C.c_size_t
-        _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, f32, f32, u32, u32, f32, u32, i32]
+        _lib.mi3d_grid_scatter_binned_workspace.argtypes = [u32, u32, f32, f32, u32, u32, f32, u32]
         _lib.mi3d_points_rasterize_workspace.restype = C.c_size_t
         _lib.mi3d_points_rasterize_workspace.argtypes = [u32, u32, u32, f32]
     return _lib

@@ -23,8 +23,8 @@ from . import _lib as L
 from . import grid_ops
 
 # Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples
-# (12 B each: 221 GiB for the 10.9 M samples x 13 points of BASELINE config 2), so samples are processed in slices
-# that fit; 120 GiB lets config 2 go in two.  It is a plain torch allocation made per call: the caching allocator
+# (180 GiB for the 10.9 M samples x 13 points of BASELINE config 2), so samples are processed in slices that fit;
+# 120 GiB lets config 2 go in two.  It is a plain torch allocation made per call: the caching allocator
 # hands the same block back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
 WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "120")) * (1 << 30))
 
@@ -37,12 +37,10 @@ def scatter_workspace(device, needed, cap=None):
     return torch.empty(want, dtype=torch.uint8, device=device) if want > 0 else None
 
 
-def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None, level_absmax=None):
+def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None):
     """grad_params [n_params] from level-major feature-gradient planes [L][P*n][2], rows point-major (C ABI:
-    mi3d_grid_scatter_binned).
-    workspace_bytes: None = scratch sized by scatter_workspace; 0 = force the all-atomic path.
-    level_absmax: float32[16] device tensor of per-level max |dplanes| (from the MLP backward) - selects the 8-byte
-    binary16 records for the fine levels; None keeps fp32 records everywhere."""
+    mi3d_grid_scatter_binned).  workspace_bytes: None = scratch sized by scatter_workspace; 0 = force the all-atomic
+    path."""
     offs, offs_p = grid_ops._offs_arg(offsets)
     P, n = offs.shape[0], x.shape[0]
     dplanes = L.dev_f32(dplanes, "dplanes")
@@ -54,7 +52,7 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     if workspace_bytes != 0 and n > 0:
         needed = lib.mi3d_grid_scatter_binned_workspace(n, P, float(bound), float(step), cfg["n_levels"],
                                                         cfg["base_resolution"], cfg["per_level_scale"],
-                                                        cfg["log2_hashmap_size"], 1 if level_absmax is not None else 0)
+                                                        cfg["log2_hashmap_size"])
         if needed:
             ws = scatter_workspace(x.device, needed, workspace_bytes)
         ws_bytes = ws.numel() if ws is not None else 0
@@ -62,15 +60,8 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
         grid_ops._timed("scatter", lambda: L.call(
             "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
             cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-            L.ptr(level_absmax), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
+            L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
     return grad
-
-
-# False (the default): 12-byte fp32 gradient records on every level - the like-for-like arithmetic (tiny-cuda-nn adds
-# fp32 products).  True: under torch.autocast(float16) the fine levels use 8-byte {entry, binary16 pair} records - the
-# upstream feature gradient is binary16 there anyway, but every corner contribution w * dfeature is then ROUNDED to
-# binary16 (gradients within ~1e-3 of the fp32 path instead of ~1e-5); an opt-in that bench.py reports as a variant.
-HALF_RECORDS = False
 
 
 def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step=0.0):
@@ -96,15 +87,11 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
     rows, plane_rows = P_active * n, feats.shape[1]
     dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
     grads = [torch.zeros_like(t) for t in ws]
-    # under autocast the feature gradients are binary16-precise: the scatter may then use its 8-byte records,
-    # scaled per level by the maxima the MLP backward collects
-    absmax = (torch.zeros(cfg["n_levels"], dtype=torch.float32, device=x.device)
-              if (half_mode and HALF_RECORDS) else None)
     grid_ops._timed("mlp_bwd", lambda: L.call(
         "mi3d_mlp_backward", L.ptr(feats), plane_rows, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, int(half_mode),
-        L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream(x)), rows)
+        L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream(x)), rows)
     gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
-                        n_params, level_absmax=absmax)
+                        n_params)
     return gp, grads
 
 

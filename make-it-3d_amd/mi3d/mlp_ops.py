@@ -41,7 +41,7 @@ class _FusedMLP(Function):
         with L.on(x):
             grid_ops._timed("mlp_bwd", lambda: L.call(
                 "mi3d_mlp_backward", L.ptr(x), 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
-                0, L.ptr(None), *[L.ptr(g) for g in grads], L.stream(x)), n)
+                0, *[L.ptr(g) for g in grads], L.stream(x)), n)
         return (dx, *grads, None)
 
 

@@ -62,17 +62,16 @@ def test_product_never_imports_the_oracle():
 
 
 def test_scatter_workspace_query_is_host_only_and_sane():
-    """mi3d_grid_scatter_binned_workspace is pure host arithmetic (no GPU): monotone in the sample count, smaller with
-    8-byte records, and at least the bytes of the records it must hold."""
+    """mi3d_grid_scatter_binned_workspace is pure host arithmetic (no GPU): monotone in the sample count and in the
+    number of stencil points, and at least the bytes of the records it must hold."""
     from mi3d import _lib
     ws = _lib.lib().mi3d_grid_scatter_binned_workspace
-    args = (13, 1.0, 2 * 3 ** 0.5 / 1024, 16, 16, 1.3819128274917603, 19)
-    full32, full16 = ws(10_878_592, *args, 0), ws(10_878_592, *args, 1)
-    half32 = ws(5_439_296, *args, 0)
-    assert 0 < full16 < full32 and half32 < full32
-    # levels 8..15 emit 8 records of 8 bytes per (evaluation, level) in the binary16 layout
-    assert full16 > 10_878_592 * 13 * 8 * 8 * 8
-    assert full32 < 300e9 and ws(0, *args, 0) == 0
+    args = (1.0, 2 * 3 ** 0.5 / 1024, 16, 16, 1.3819128274917603, 19)
+    full, half_n, one_pt = ws(10_878_592, 13, *args), ws(5_439_296, 13, *args), ws(10_878_592, 1, *args)
+    assert 0 < half_n < full and one_pt < full / 8
+    # levels 8..15 emit 4 x-pair records of 16 bytes per (evaluation, level)
+    assert full > 10_878_592 * 13 * 8 * 4 * 16
+    assert full < 300e9 and ws(0, 13, *args) == 0
 
 
 def test_product_library_reads_no_environment_and_has_no_dev_hooks():

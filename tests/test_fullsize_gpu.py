@@ -53,11 +53,8 @@ def test_c2_full_size_march_invariants_and_gather_scatter_adjoint(cuda, oracle):
     g = torch.empty(16, m * P, 2, device=cuda).uniform_(0.5, 1.5)
     lhs = sum(float(torch.dot(feats[l].reshape(-1).double(), g[l].reshape(-1).double())) for l in range(16))
     del feats
-    for half in (False, True):
-        absmax = g.amax(dim=(1, 2)).contiguous() if half else None
-        grad = field_ops.scatter_binned(x, x2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, n_params, level_absmax=absmax)
-        rhs = float(torch.dot(params.double(), grad.double()))
-        tol = 1e-3 if half else 1e-5   # binary16 records round each contribution to 11 bits (unbiased: errors average)
-        assert abs(lhs - rhs) <= tol * abs(lhs), (half, lhs, rhs)
-        # all contributions are positive; the view frustum crosses about a fifth of the coarsest level's entries
-        assert float(grad.min()) >= 0.0 and float((grad[: 4096 * 2] > 0).float().mean()) > 0.1
+    grad = field_ops.scatter_binned(x, x2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, n_params)
+    rhs = float(torch.dot(params.double(), grad.double()))
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (lhs, rhs)
+    # all contributions are positive; the view frustum crosses about a fifth of the coarsest level's entries
+    assert float(grad.min()) >= 0.0 and float((grad[: 4096 * 2] > 0).float().mean()) > 0.1

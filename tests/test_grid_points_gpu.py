@@ -142,7 +142,7 @@ def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace
     if ws == "tiny":  # room for about a third of the samples per slice
         import ctypes
         from mi3d import _lib
-        need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19, 0)
+        need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19)
         ws = int(need)
     g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda) if second else None, offs, P0, bound, T(planes, cuda), kcfg,
                                  0.0034, cfg.n_params, workspace_bytes=ws).cpu().numpy()
@@ -187,73 +187,8 @@ def test_field_stencil_node_equals_layer_composition(cuda, oracle):
         assert float((a - b).abs().max()) <= (2e-4 if i >= 5 else 2e-5) * scale, i
 
 
-@pytest.mark.parametrize("workspace", ["auto", "tiny"])
-def test_binned_scatter_half_records_match_oracle(cuda, oracle, workspace):
-    """The 8-byte-record path (fine levels as {entry, binary16 pair} scaled per level, line-staged emit) - what the
-    fused field node uses under torch.autocast.  Tolerance: binary16 resolution of each contribution."""
-    from mi3d import field_ops, grid_ops
-    rng = np.random.default_rng(24)
-    cfg = oracle.GridConfig()
-    kcfg = dict(n_levels=16, base_resolution=16, per_level_scale=cfg.per_level_scale, log2_hashmap_size=19)
-    n = 6000
-    x = _ray_like_points(rng, n, 1.0)
-    x2 = (x + rng.normal(size=x.shape).astype(np.float32) * np.float32(0.01)).astype(np.float32)
-    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
-    P = offs.shape[0]
-    # per-level magnitudes spread over 12 decades, plus rows of zeros
-    mag = (10.0 ** rng.uniform(-8, 4, 16)).astype(np.float32)
-    dout = (rng.normal(size=(n, P, 16, 2)).astype(np.float32) * mag[None, None, :, None]).astype(np.float32)
-    dout[100:140] = 0
-    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
-    absmax = T(np.abs(planes).reshape(16, -1).max(1).astype(np.float32), cuda)
-    ws = None
-    if workspace == "tiny":
-        from mi3d import _lib
-        ws = int(_lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19, 1))
-    g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda), offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params,
-                                 workspace_bytes=ws, level_absmax=absmax).cpu().numpy()
-    ref = np.zeros(cfg.n_params, np.float64)
-    for p, pts in enumerate(_points(x, x2, offs, P0, 1.0)):
-        h01 = ((pts + np.float32(1.0)) / np.float32(2.0)).astype(np.float32)
-        ref += oracle.hashgrid_backward(h01, dout[:, p].reshape(n, 32), cfg)
-    for l in range(16):
-        a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
-        scale = np.abs(ref[a:b]).max()
-        tol = 2e-5 if l < 8 else 2e-3   # levels with cells shorter than 3 steps (>= 8 here) carry binary16 records
-        assert np.abs(g[a:b] - ref[a:b]).max() <= tol * scale + 1e-30, (l, np.abs(g[a:b] - ref[a:b]).max(), scale)
-
-
-def test_binned_scatter_half_records_axis_parallel_rays(cuda, oracle):
-    """Samples marching along +x keep (y, z) lattice coordinates - and with them the hash bin - for whole waves: all 64
-    lanes of an append hit ONE bin, far more than a staging ring holds.  (This input hung the first staged emit.)"""
-    from mi3d import field_ops, grid_ops
-    rng = np.random.default_rng(31)
-    cfg = oracle.GridConfig()
-    kcfg = dict(n_levels=16, base_resolution=16, per_level_scale=cfg.per_level_scale, log2_hashmap_size=19)
-    n = 4096
-    t = (np.arange(n) % 512)[:, None] * np.float32(0.0034)
-    x = np.concatenate([-0.85 + t, np.full((n, 1), 0.3137, np.float32) + (np.arange(n) // 512)[:, None] * 0.05,
-                        np.full((n, 1), -0.2241, np.float32)], 1).astype(np.float32)
-    offs, P0 = grid_ops.stencil_offsets(center=True, second=False)
-    P = offs.shape[0]
-    dout = rng.normal(size=(n, P, 16, 2)).astype(np.float32)
-    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
-    absmax = T(np.abs(planes).reshape(16, -1).max(1).astype(np.float32), cuda)
-    g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params,
-                                 level_absmax=absmax).cpu().numpy()
-    ref = np.zeros(cfg.n_params, np.float64)
-    for p, pts in enumerate(_points(x, x, offs, P0, 1.0)):
-        ref += oracle.hashgrid_backward(((pts + np.float32(1.0)) / np.float32(2.0)).astype(np.float32),
-                                        dout[:, p].reshape(n, 32), cfg)
-    for l in range(16):
-        a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
-        scale = np.abs(ref[a:b]).max()
-        assert np.abs(g[a:b] - ref[a:b]).max() <= (2e-5 if l < 8 else 2e-3) * scale + 1e-30, l
-
-
 @pytest.mark.parametrize("bad", ["inf", "nan"])
-@pytest.mark.parametrize("half", [False, True])
-def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad, half):
+def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad):
     """A non-finite feature gradient must reach encoder.params.grad (GradScaler's overflow check reads it there): the
     reference's float atomics would put the inf / NaN into the table; the record path poisons the whole level with NaN
     and leaves the other levels exact."""
@@ -270,12 +205,7 @@ def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad, half)
     for lvl in (3, 12):   # one run-merged coarse level, one fine level
         dout[777, 2, lvl, 1] = np.inf if bad == "inf" else np.nan
     planes = T(np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2)), cuda)
-    absmax = None
-    if half:   # what mi3d_mlp_backward writes: +inf for a level holding a non-finite value
-        a = planes.abs().amax(dim=(1, 2))
-        absmax = torch.where(torch.isfinite(a), a, torch.full_like(a, float("inf"))).contiguous()
-    g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, planes, kcfg, 0.0034, cfg.n_params,
-                                 level_absmax=absmax).cpu().numpy()
+    g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, planes, kcfg, 0.0034, cfg.n_params).cpu().numpy()
     ref = np.zeros(cfg.n_params, np.float64)
     for p, pts in enumerate(_points(x, x, offs, P0, 1.0)):
         ref += oracle.hashgrid_backward(((pts + np.float32(1.0)) / np.float32(2.0)).astype(np.float32),
@@ -285,7 +215,7 @@ def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad, half)
         if l in (3, 12):
             assert not np.isfinite(g[a:b]).all(), l
         else:
-            tol = 2e-3 if (half and l >= 8) else 2e-5
+            tol = 2e-5
             assert np.isfinite(g[a:b]).all() and np.abs(g[a:b] - ref[a:b]).max() <= tol * np.abs(ref[a:b]).max(), l
 
 

@@ -1,7 +1,7 @@
 """One C2 view through the product's NeRF kernels only - march, 13-point field (gather, MLP, head), composite, the
 two backward passes of the reference's SDS schedule (point 0 only, then all 13 points) - without the diffusion
 networks: the command the rocprofv3 kernel-trace / PMC passes of profiles/ are collected on.
-    python tools/field_bench.py [--iters 2] [--workload c2_dense] [--records fp32|half]"""
+    python tools/field_bench.py [--iters 2] [--workload c2_dense]"""
 import argparse
 import os
 import sys
@@ -16,7 +16,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--workload", default="c2_dense")
-    ap.add_argument("--records", default="fp32", choices=["fp32", "half"])
     a = ap.parse_args()
     import bench
     from mi3d import field_ops, rays as R, sds_step
@@ -24,7 +23,6 @@ def main():
     dev = torch.device("cuda:0")
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
     model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"], init_scale=0.25)
-    field_ops.HALF_RECORDS = a.records == "half"
     ro, rd, ds = R.view_rays(wl["H"], wl["W"], device=dev)
     for i in range(a.iters):
         torch.cuda.synchronize()

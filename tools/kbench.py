@@ -109,11 +109,10 @@ def main():
         dh = torch.randn(P * n, 4, device=dev)
         dplanes = torch.empty(16, P * n, 2, device=dev)
         grads = [torch.zeros_like(t) for t in ws]
-        absmax = torch.zeros(16, device=dev)
 
         def bwd(rows=P * n):
             L.call("mi3d_mlp_backward", L.ptr(feats), P * n, L.ptr(dh), rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1,
-                   L.ptr(dplanes), rows, L.ptr(absmax), *[L.ptr(g) for g in grads], L.stream())
+                   L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream())
         for v in (0, 1, 2):   # 0: two tiles per wave (staged), 1: one tile per wave, 2: one tile, 2 waves/SIMD (spills)
             tune(6, v)
             for w in ((2, 4) if v == 2 else (1, 2)):
@@ -129,10 +128,8 @@ def main():
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
         g = torch.randn(16, P * n, 2, device=dev)
-        absmax = g.abs().amax(dim=(1, 2)).contiguous()
-        for name, am in (("fp32", None), ("half", absmax)):
-            res[f"scatter_{name}_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
-                xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240, level_absmax=am), a.iters)
+        res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
+            xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
         g1 = g[:, :n].contiguous()
         res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
