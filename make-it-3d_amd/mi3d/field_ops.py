@@ -30,10 +30,14 @@ WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "120
 
 
 def scatter_workspace(device, needed, cap=None):
-    """uint8 scratch of min(needed, cap, 45 % of the device's memory) bytes from torch's caching allocator (or None)."""
+    """uint8 scratch of min(needed, cap, 45 % of the device's memory) bytes from torch's caching allocator (or None).
+    The request is rounded up to a whole GiB so that the sample count drifting from step to step does not leave the
+    caching allocator with a trail of slightly different multi-GiB blocks (measured: 2 slices of 120 GiB cost 75 ms per
+    141 M evaluations, 4 slices of 60 GiB 80 ms)."""
     cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
     total = torch.cuda.get_device_properties(device).total_memory
-    want = min(int(needed), cap, int(total * 0.45))
+    gib = 1 << 30
+    want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(total * 0.45))
     return torch.empty(want, dtype=torch.uint8, device=device) if want > 0 else None
 
 
