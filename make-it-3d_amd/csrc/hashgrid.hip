@@ -121,20 +121,22 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 // Output is level-major planes [L][P*n][2], row = p*n + s (point-major): the 64 lanes of a wave store 512 contiguous
 // bytes per point, and the MLP kernels read them with x_plane_rows = P*n.
 //
-// What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level, profiles/kbench_r02.json): levels 0-7
-// cost 1.15-1.3 ms each, then the cost climbs with the number of distinct lines a wave's 64 consecutive samples touch -
-// 1.6 / 2.0 / 2.6 / 3.3 / 3.6 ms for levels 8-12 - and saturates at 3.8 ms (4.06 without pair loads) for levels 13-15,
-// where every lane is in its own line: 141 M evaluations x 8 corners x one 128-byte line from the L2 = 145 GB per level
-// against the L2s' ~34.5 TB/s (MI355X_MICROARCH.md) = 4.2 ms.  The gather is L2->L1 line-bandwidth bound (16x the bytes
-// it uses); the levels sum to 34 ms, the launch takes 39.5 ms with the segments below.
-// Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
-// per CU (+3 ms); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the coarse
-// levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
-// What is kept:
+// What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level, profiles/kbench_r02_*.json): levels
+// 0-7 cost 1.15-1.3 ms each, then the cost climbs with the number of distinct lines a wave's 64 consecutive samples
+// touch - 1.4 / 1.7 / 2.4 / 3.0 / 3.3 ms for levels 8-12 - and saturates at 3.5 ms for levels 13-15 (4.06 with eight
+// separate 8-byte loads), where every lane is in its own line: 141 M evaluations x 8 corners x one 128-byte line from
+// the L2 = 145 GB per level against the L2s' ~34.5 TB/s (MI355X_MICROARCH.md) = 4.2 ms.  The gather is L2->L1
+// line-bandwidth bound (16x the bytes it uses), so what helps is not asking the L2 twice for a line:
 //   PAIR   the x and x+1 corners of a (y, z) corner pair are neighbours in memory whenever their entry indices differ
 //          in bit 0 only - every even cx on hashed levels (x enters the hash with prime 1), every even entry index on
-//          dense ones: one 16-byte load of the aligned slot serves both, the x+1 corner is fetched separately only
-//          where the pair straddles a slot (-10 % on the saturated levels, 44.7 -> 39.5 ms per launch).
+//          dense ones: one 16-byte load of the aligned slot serves both (44.7 -> 39.5 ms per launch);
+//   ORDER  where the pair straddles a slot, the x+1 corner still sits in the same 128-byte line 15 times out of 16;
+//          its load is issued DIRECTLY behind the slot's, so it merges with the pending miss instead of finding the
+//          line evicted again by the other 60 lanes' lines (32 KB of L1 against 64 KB of lines per point): 39.5 ->
+//          35.6 ms, saturated levels 3.8 -> 3.5 ms.
+// Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
+// per CU (+2-6 ms); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the
+// coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
 
@@ -159,12 +161,16 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
     for (uint32_t j = 0; j < 4; ++j) {
         e0[j] = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
         e1[j] = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
-        // the aligned 16-byte slot holding entry e0 (level bases and sizes are multiples of 8 entries)
-        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u));
     }
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j)  // the x+1 corner only where it is not the other half of that slot
+    for (uint32_t j = 0; j < 4; ++j) {
+        // the aligned 16-byte slot holding entry e0 (level bases and sizes are multiples of 8 entries) ...
+        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0[j] & ~1u));
+        // ... and, right behind it, the x+1 corner where it is not the other half of that slot: 15 times out of 16 it
+        // sits in the same 128-byte line (x only touches the low index bits), and a request issued while that line's
+        // miss is still pending merges with it instead of fetching the line from the L2 a second time
         if ((e0[j] ^ e1[j]) != 1u) v[2 * j + 1] = lvl[e1[j]];
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const bool odd = e0[j] & 1u;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
 inline double encode_level_cost(double x) {
     static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
-    static const double cs[] = {1.17, 1.18, 1.22, 1.31, 1.56, 2.00, 2.64, 3.26, 3.63, 3.75, 3.80, 3.79};
+    static const double cs[] = {1.17, 1.18, 1.22, 1.28, 1.42, 1.74, 2.36, 2.99, 3.35, 3.46, 3.49, 3.51};
     constexpr int N = sizeof(xs) / sizeof(xs[0]);
     if (x <= xs[0]) return cs[0];
     for (int i = 1; i < N; ++i)
