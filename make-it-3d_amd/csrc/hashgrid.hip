@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 //          line evicted again by the other 60 lanes' lines (32 KB of L1 against 64 KB of lines per point): 39.5 ->
 //          35.6 ms, saturated levels 3.8 -> 3.5 ms.
 // Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
-// per CU (+2-6 ms); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the
+// per CU (+2-6 ms); evaluating the stencil three points at a time with the +-eps x-neighbours adjacent and all 24 loads
+// in flight (35.6 -> 36.0 ms: the coarse levels lose to the lower occupancy what the fine ones gain); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the
 // coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
