@@ -512,7 +512,7 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
-constexpr uint32_t kEmitWavesMax = 1024, kReduceSplit = 4;
+constexpr uint32_t kEmitWavesMax = 1024;
 
 struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index
@@ -817,10 +817,13 @@ __device__ __forceinline__ void poison_bin(const GridLevel &L, uint32_t lb, floa
 __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *__restrict__ arena,
                                                                      const uint32_t *__restrict__ counts,
                                                                      const float *__restrict__ level_max, GridTable T,
-                                                                     BinPlan plan, float *__restrict__ grad_table) {
+                                                                     BinPlan plan, uint32_t n_split,
+                                                                     float *__restrict__ grad_table) {
     extern __shared__ unsigned long long acc[];  // [kBinEntries * 2]
     __shared__ float wg_max[kReduceWaves];
-    const uint32_t b = blockIdx.x / kReduceSplit, split = blockIdx.x % kReduceSplit;
+    // n_split workgroups share a bin (each takes every n_split-th group of emitting waves): 4 for a full-size pass, 1 for
+    // a small one (the point-0 pass of the SDS backward), where zeroing and flushing the 128 KB tile is most of the work
+    const uint32_t b = blockIdx.x / n_split, split = blockIdx.x % n_split;
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = threadIdx.x / kWave;
     uint32_t lvl = 0;  // which level does this bin belong to?  (uniform scan of at most 16 entries)
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 
     bool any = false;
     constexpr uint32_t U = 8;  // records in flight per lane
-    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += kReduceSplit * kReduceWaves) {
+    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
         const uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
         if (row) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
@@ -1104,8 +1107,9 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
             hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
                                (uint32_t)s0, s1, dout_planes, plane_rows, n, T, plan, merge_levels, fine_mask, fine_waves,
                                coarse_mask, coarse_waves, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
-        hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * kReduceSplit), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
-                           counts, level_max, T, plan, grad_params);
+        const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
+        hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * n_split), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
+                           counts, level_max, T, plan, n_split, grad_params);
     }
     return (int)hipGetLastError();
 }
