@@ -502,9 +502,11 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         of its BIN (8192 consecutive entries of one level = 64 KB of gradient).  One private
 //                         region per (wave, bin): an append is a wave-private LDS counter and a plain store.  The
 //                         arena is wave-major so the regions a wave is filling at any moment (one level's bins) sit
-//                         in a few MB: a handful of TLB pages, and with ~1000 emitting waves the lines being
-//                         appended to fit the L2s (round 2, 16-byte pair records, 141 M evaluations: 256 waves 175 ms,
-//                         512: 110, 768: 89, 1024: 79, 1536: 80, 2048: 86, 4096: 94).
+//                         in a few MB: a handful of TLB pages, and with ~1500 emitting waves the lines being
+//                         appended to fit the L2s (round 2, 16-byte pair records, 141 M evaluations with dense random
+//                         gradients: 256 waves 175 ms, 512: 110, 768: 89, 1024: 79, 1536: 80, 2048: 86, 4096: 94; with
+//                         the gradients of a real step - whole iteration of tools/field_bench.py - 768: 130, 1024: 118.5,
+//                         1536: 114.0, 2048: 114.3, 3072: 115.6, 4096: 118.2).
 //                         On levels whose cells are longer than a marching step, equal-cell RUNS of consecutive
 //                         lanes are summed first (through an LDS slab, see k_scatter_runs) and emit one record set.
 //   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS in
@@ -512,7 +514,7 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
-constexpr uint32_t kEmitWavesMax = 1024;
+constexpr uint32_t kEmitWavesMax = 1536;
 
 struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index
@@ -551,7 +553,7 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
     return nw ? nw : kWaves;
 }
 
-// The plan for slices of n_slice samples.  Fine levels are emitted by at most 1024 waves (the lines being appended to
+// The plan for slices of n_slice samples.  Fine levels are emitted by at most 1536 waves (the lines being appended to
 // must fit the L2s); the coarse levels' run merging is latency-bound and emits few records, so it gets up to 16384.
 // Region capacities - hashed levels: the uniform share of the UNMERGED record count plus 25 % (the hash spreads them
 // evenly).  Dense levels: bins are spatial, a wave's samples cluster in few of them, and merging thins the records by

@@ -9,6 +9,20 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "make-it-3d_amd")]
+
+
+def _dev_tunables(spec):
+    """--dev 3=2048,4=8192: load the -DMI3D_DEV build (tools/build_dev.py) and set its tunables (csrc/mi3d_dev.h)."""
+    import ctypes as C
+    os.environ["MI3D_LIB"] = os.path.join(ROOT, "tools", "bin", "libmi3d_dev.so")
+    from mi3d import _lib as L
+    lib = L.lib()
+    lib.mi3d_dev_set.argtypes = [C.c_int, C.c_int]
+    for kv in spec.split(","):
+        k, v = kv.split("=")
+        lib.mi3d_dev_set(int(k), int(v))
+
+
 import torch  # noqa: E402
 
 
@@ -16,7 +30,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--workload", default="c2_dense")
+    ap.add_argument("--dev", default="", help="development build tunables, e.g. 3=2048 (emit fine waves)")
     a = ap.parse_args()
+    if a.dev:
+        _dev_tunables(a.dev)
     import bench
     from mi3d import field_ops, rays as R, sds_step
     wl = bench.WORKLOADS[a.workload]
