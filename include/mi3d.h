@@ -161,11 +161,17 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
 /* mi3d_grid_encode_points with level-major output planes [n_levels][P*n][2] (feature pair of level l, row r = p*n + i
  * at out_planes[(l*P*n + r)*2]) - the layout the MLP kernels take with x_plane_rows = P*n.  The (level, tile) work is
  * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from; `step` (the marching
- * step in world units, 0 = unknown) only balances that split, never the result. */
+ * step in world units, 0 = unknown) only balances that split, never the result.
+ * PLANE ELEMENT TYPE: out_half == 0: fp32 pairs (8 bytes per (level, row)); out_half != 0: binary16 pairs (4 bytes) -
+ * for use under torch.autocast(float16) only, where the first nn.Linear rounds its input to binary16 anyway
+ * (mi3d_mlp_forward / _backward with half_mode != 0 read them with planes_half != 0: same MLP output, bit for bit,
+ * half the bytes).  The gradient planes mi3d_mlp_backward writes follow the same flag: the input gradient of that
+ * Linear comes out of a binary16 GEMM in the reference, so binary16 planes hold exactly what autocast would hand the
+ * encoder's backward. */
 int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
                                    uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
-                                   float *out_planes, void *stream);
+                                   void *out_planes, int out_half, void *stream);
 int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
                              const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
@@ -177,14 +183,14 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
  * added to the table (see hashgrid.hip).  fp32 contributions throughout; a level that receives a non-finite
  * contribution is filled with NaN (what the float atomics of the reference would have left in the table).
  * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
- * dx_plane_rows = P*n).
+ * dx_plane_rows = P*n); dout_half != 0: binary16 pairs (see mi3d_grid_encode_points_planes).
  * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
  * it; with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
  * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice. */
 size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
                                           uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size);
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
-                             uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
+                             uint32_t P, float bound, const void *dout_planes, int dout_half, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                              void *workspace, size_t workspace_bytes, float *grad_params, void *stream);
 
@@ -192,24 +198,25 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
 
 /* network_tcnn.py:13-32: y = W3 relu(W2 relu(W1 x + b1) + b2) + b3, torch nn.Linear layout (W_l is [out_l, in_l]
  * row-major fp32, the master weights).  x [n, dim_in] fp32 rows (x_plane_rows == 0), or level-major planes
- * [dim_in/2][x_plane_rows][2] of which the first n rows are processed (x_plane_rows >= n); out [n, dim_out] fp32.
+ * [dim_in/2][x_plane_rows][2] of which the first n rows are processed (x_plane_rows >= n; planes_half != 0: the planes
+ * hold binary16 pairs, half_mode only - applies to x and, in the backward, to dx alike); out [n, dim_out] fp32.
  * half_mode != 0 reproduces torch.autocast(float16) around the stack (nerf/utils.py:979): inputs, weights, biases
  * and every layer output are rounded to binary16, products accumulate in fp32 (v_mfma_f32_32x32x16_f16);
  * half_mode == 0 is exact fp32 (v_mfma_f32_32x32x2_f32).  Supported shape: dim_in 32, dim_hidden 64, dim_out 4,
  * three layers (what network_tcnn.py:67 builds for the default 16-level grid); anything else returns
  * hipErrorInvalidValue - ask mi3d_mlp_supported() first. */
 int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, uint32_t num_layers);
-int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const float *W1, const float *b1,
-                     const float *W2, const float *b2,
+int mi3d_mlp_forward(const void *x, uint32_t x_plane_rows, int planes_half, uint32_t n, const float *W1,
+                     const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream);
 /* Backward of the above for upstream gradient dout [n, dim_out]: writes dx and ACCUMULATES the weight and bias
  * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
  * dx_plane_rows == 0: dx is [n, dim_in] rows; otherwise dx is level-major planes [dim_in/2][dx_plane_rows][2]
  * (feature pair (2l, 2l+1) of row r at dx[(l*dx_plane_rows + r)*2]), the layout mi3d_grid_scatter_binned consumes. */
-int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1,
-                      const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
-                      uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx,
+int mi3d_mlp_backward(const void *x, uint32_t x_plane_rows, int planes_half, const float *dout, uint32_t n,
+                      const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                      const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, int half_mode, void *dx,
                       uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream);
 

@@ -260,10 +260,18 @@ __device__ void build_blocks(char *lds, float *bias /* [HID + HID + 32] */, cons
 // Rows past n are read from row n - 1 instead of being predicated off (no exec-mask branches around the loads, so all
 // of them are in flight together); their products are harmless: every weight-gradient term carries a factor dout,
 // which IS zeroed for those rows, and their outputs are never stored.
+// planes_half: the planes hold binary16 pairs (4 bytes per (level, row)) - see plane layouts in include/mi3d.h.
 __device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_t row, size_t n, int h,
-                                              size_t plane_rows, float (&raw)[16]) {
+                                              size_t plane_rows, float (&raw)[16], int planes_half = 0) {
     row = row < n ? row : n - 1;
-    if (plane_rows == 0) {
+    if (plane_rows != 0 && planes_half) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // 32 consecutive rows of one plane per load: 128 contiguous bytes per lane-half
+            const uint32_t u = reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row];
+            raw[2 * j] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu));
+            raw[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+        }
+    } else if (plane_rows == 0) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -288,9 +296,9 @@ template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float
 }
 template <class P>
 __device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__ x, size_t row, size_t n, int h,
-                                                       size_t plane_rows) {
+                                                       size_t plane_rows, int planes_half) {
     float raw[16];
-    load_rows_raw(x, row, n, h, plane_rows, raw);
+    load_rows_raw(x, row, n, h, plane_rows, raw, planes_half);
     return rows_kb<P>(raw);
 }
 
@@ -321,8 +329,8 @@ __device__ __forceinline__ f32x16 bias_rows(const float *bias, int h) {
 }
 // ---------------------------------------------------------------- forward
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t x_planes, uint32_t n,
-                                                                     Weights w, float *__restrict__ out) {
+__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t x_planes, int x_half,
+                                                                     uint32_t n, Weights w, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_FWD_COUNT * block_bytes<P>());
     build_blocks<P>(lds, bias, w, B_FWD_COUNT);
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const size_t row = (size_t)tile * 32 + p;
         const bool valid = row < n;
-        const typename P::KB X = load_rows_kb<P>(x, row, n, h, x_planes);
+        const typename P::KB X = load_rows_kb<P>(x, row, n, h, x_planes, x_half);
         typename P::KB H1[NTH], H2[NTH];
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
@@ -382,8 +390,8 @@ struct Grads {
 // overlap (the packed converts of one accumulator run under the MFMAs of the next).
 template <class P, int U, int WPS>
 __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
-                                                                           const float *__restrict__ dout, uint32_t n,
-                                                                           Weights w, float *__restrict__ dx,
+                                                                           int planes_half, const float *__restrict__ dout,
+                                                                           uint32_t n, Weights w, float *__restrict__ dx,
                                                                            uint32_t dx_planes, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_ALL_COUNT * block_bytes<P>());
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const size_t r0 = ((size_t)wave + (size_t)u * n_waves) * 32 + p;
-        load_rows_raw(x, r0, n, h, x_planes, raw[u]);
+        load_rows_raw(x, r0, n, h, x_planes, raw[u], planes_half);
         dor[u] = load_dout_raw(dout, r0, n);
     }
     for (uint32_t tile = wave; tile < n_tiles; tile += U * n_waves) {
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t rn = ((size_t)tile + (size_t)(U + u) * n_waves) * 32 + p;
-                load_rows_raw(x, rn, n, h, x_planes, raw[u]);
+                load_rows_raw(x, rn, n, h, x_planes, raw[u], planes_half);
                 dor[u] = load_dout_raw(dout, rn, n);
             }
         }
@@ -547,6 +555,17 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
                     for (int c = 0; c < 4; ++c) {
                         f32x4 o = {acc[u][4 * c], acc[u][4 * c + 1], acc[u][4 * c + 2], acc[u][4 * c + 3]};
                         __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
+                    }
+                } else if (valid[u] && planes_half) {
+                    // binary16 planes: one 4-byte store per (level, row); this IS the rounding torch.autocast gives the
+                    // input gradient of the first nn.Linear (a binary16 GEMM output)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const size_t lvl = 4 * c + 2 * h;
+                        const half2v a = __builtin_convertvector((f32x2){acc[u][4 * c], acc[u][4 * c + 1]}, half2v);
+                        const half2v b = __builtin_convertvector((f32x2){acc[u][4 * c + 2], acc[u][4 * c + 3]}, half2v);
+                        reinterpret_cast<uint32_t *>(dx)[lvl * dx_planes + row[u]] = __builtin_bit_cast(uint32_t, a);
+                        reinterpret_cast<uint32_t *>(dx)[(lvl + 1) * dx_planes + row[u]] = __builtin_bit_cast(uint32_t, b);
                     }
                 } else if (valid[u]) {
                     // level-major planes [DIN/2][dx_planes][2] (what the binned scatter reads): features (2l, 2l+1) of
@@ -901,29 +920,35 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
     return dims_ok(dim_in, dim_hidden, dim_out, num_layers) ? 1 : 0;
 }
 
-int mi3d_mlp_forward(const float *x, uint32_t x_plane_rows, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+int mi3d_mlp_forward(const void *xv, uint32_t x_plane_rows, int planes_half, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream) {
-    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n)) return (int)hipErrorInvalidValue;
+    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
+        (planes_half && (x_plane_rows == 0 || !half_mode)))
+        return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
+    const float *x = reinterpret_cast<const float *>(xv);
     const Weights w{W1, b1, W2, b2, W3, b3};
     if (half_mode)
         hipLaunchKernelGGL(k_mlp_forward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, n, w, out);
+                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, planes_half, n, w, out);
     else
         hipLaunchKernelGGL(k_mlp_forward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, n, w, out);
+                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, planes_half, n, w, out);
     return (int)hipGetLastError();
 }
 
-int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, uint32_t n, const float *W1, const float *b1,
+int mi3d_mlp_backward(const void *xv, uint32_t x_plane_rows, int planes_half, const float *dout, uint32_t n, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
-                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, float *dx, uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
+                      uint32_t dim_hidden, uint32_t dim_out, int half_mode, void *dxv, uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream) {
     if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
-        (dx_plane_rows != 0 && dx_plane_rows < n))
+        (dx_plane_rows != 0 && dx_plane_rows < n) ||
+        (planes_half && (x_plane_rows == 0 || dx_plane_rows == 0 || !half_mode)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
+    const float *x = reinterpret_cast<const float *>(xv);
+    float *dx = reinterpret_cast<float *>(dxv);
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     const dim3 grid(grid_for(n)), block(kWave * kWavesPerWG);
@@ -931,22 +956,22 @@ int mi3d_mlp_backward(const float *x, uint32_t x_plane_rows, const float *dout, 
 #ifdef MI3D_DEV
     const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
     if (half_mode && variant == 1) {  // one tile at a time
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, g);
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+                           dout, n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
     if (half_mode && variant == 2) {  // one tile at a time, two waves per SIMD (256 registers, spills)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 2>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, g);
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 2>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+                           dout, n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
 #endif
     if (half_mode)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, g);
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+                           dout, n, w, dx, dx_plane_rows, g);
     else
-        hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, dout,
-                           n, w, dx, dx_plane_rows, g);
+        hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+                           dout, n, w, dx, dx_plane_rows, g);
     return (int)hipGetLastError();
 }
 

@@ -66,6 +66,27 @@ __device__ __forceinline__ void point_of(const PointSet &ps, const float (&b)[2]
     }
 }
 
+// Feature / gradient planes hold one pair per (level, row): fp32 (8 bytes) or - under torch.autocast(float16), where
+// the MLP's first layer rounds its input to binary16 and its input gradient comes out of a binary16 GEMM anyway -
+// binary16 (4 bytes): the same values the fp32 planes would hold after the rounding autocast applies to them.
+__device__ __forceinline__ float2 plane_pair(const float *planes, int half, size_t i) {
+    if (half) {
+        const uint32_t u = reinterpret_cast<const uint32_t *>(planes)[i];
+        return make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu)),
+                           (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)));
+    }
+    return reinterpret_cast<const float2 *>(planes)[i];
+}
+__device__ __forceinline__ void store_plane_pair(float *planes, int half, size_t i, float a, float b) {
+    if (half) {
+        const uint32_t u = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)a) |
+                           ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+        reinterpret_cast<uint32_t *>(planes)[i] = u;
+    } else {
+        reinterpret_cast<float2 *>(planes)[i] = make_float2(a, b);
+    }
+}
+
 // ---------------------------------------------------------------- forward
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint32_t n, const int32_t *count,
                                                                 const float2 *__restrict__ table, GridTable T,
@@ -183,7 +204,8 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
 template <bool PAIR>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
-                                                                       EncodePlan plan, float2 *__restrict__ planes) {
+                                                                       EncodePlan plan, float *__restrict__ planes,
+                                                                       int out_half) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         const uint32_t l = seg.level;
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
-        float2 *plane = planes + (size_t)l * rows_total;
+        const size_t plane0 = (size_t)l * rows_total;
         for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
             const uint32_t s = tile * kTile + lane;
             if (s >= n) continue;
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                 float r0 = 0.f, r1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
-                plane[(size_t)p * n + s] = make_float2(r0, r1);
+                store_plane_pair(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
             }
         }
     }
@@ -304,8 +326,8 @@ __device__ __forceinline__ bool quad_merge_runs(bool active, const CellKey &key,
 __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t n, const int32_t *count,
                                                             const float *__restrict__ dout, GridTable T,
                                                             uint32_t merge_levels, uint32_t level_mask,
-                                                            uint32_t plane_rows, uint32_t n_rep, size_t rep_stride,
-                                                            float *__restrict__ grad_table) {
+                                                            uint32_t plane_rows, int planes_half, uint32_t n_rep,
+                                                            size_t rep_stride, float *__restrict__ grad_table) {
     // n_rep > 1: grad_table is a stack of n_rep private copies (rep_stride floats apart) of the table prefix the
     // selected levels live in; workgroup b adds into copy b % n_rep.  The few lines of a coarse level are hit by every
     // workgroup, and atomics on ONE line serialise at the memory side (~0.3 us each, profiles/scatter_levels_r01.json);
@@ -335,7 +357,15 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter(PointSet ps, uint32_t
                 if (!((level_mask >> l) & 1u)) continue;
                 const GridLevel L = T.level[l];
                 // dout is either [rows, 2L] or (plane_rows != 0) level-major planes [L][plane_rows][2]
-                const float d = !valid ? 0.f : plane_rows ? dout[((size_t)l * plane_rows + row) * 2 + f] : drow[2 * l];
+                float d = 0.f;
+                if (valid) {
+                    if (plane_rows) {
+                        const float2 dd = plane_pair(dout, planes_half, (size_t)l * plane_rows + row);
+                        d = f ? dd.y : dd.x;
+                    } else {
+                        d = drow[2 * l];
+                    }
+                }
                 // a row whose two feature gradients are both zero (padding, masked samples) is skipped
                 const float d_other = __shfl_xor(d, 1, 64);  // the quad's other feature (unconditional: all lanes)
                 const bool has = valid && (d != 0.f || d_other != 0.f);
@@ -376,7 +406,7 @@ constexpr int kRunStride = 17;  // floats per lane in the slab (16 values, padde
 
 __global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uint32_t n, const float *__restrict__ dout,
                                                                  GridTable T, uint32_t level_mask, uint32_t plane_rows,
-                                                                 uint32_t n_rep, size_t rep_stride,
+                                                                 int planes_half, uint32_t n_rep, size_t rep_stride,
                                                                  float *__restrict__ grad_table) {
     __shared__ float slab_all[kWaves][kWave * kRunStride];
     __shared__ uint32_t cell_all[kWaves][kWave * 3];   // cell of every lane
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_scatter_runs(PointSet ps, uin
             const size_t row = (size_t)p * n + s;  // point-major rows
             float d0 = 0.f, d1 = 0.f;
             if (valid) {
-                const float2 dd = plane_rows ? reinterpret_cast<const float2 *>(dout)[(size_t)l * plane_rows + row]
+                const float2 dd = plane_rows ? plane_pair(dout, planes_half, (size_t)l * plane_rows + row)
                                              : *reinterpret_cast<const float2 *>(dout + row * F + 2 * l);
                 d0 = dd.x; d1 = dd.y;
             }
@@ -465,7 +495,7 @@ PointSet make_points(const float *x, const float *x2, const float *offsets_host,
 
 int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const float *dout, const GridTable &T,
                    uint32_t merge_levels, float *grad_params, hipStream_t st, uint32_t level_mask = 0xFFFFFFFFu,
-                   uint32_t plane_rows = 0, uint32_t n_rep = 1, size_t rep_stride = 0) {
+                   uint32_t plane_rows = 0, uint32_t n_rep = 1, size_t rep_stride = 0, int planes_half = 0) {
     merge_levels = (uint32_t)MI3D_TUNE(MI3D_T_SCATTER_MERGE, merge_levels);
     if (merge_levels > T.n_levels) merge_levels = T.n_levels;
     level_mask &= (uint32_t)MI3D_TUNE(MI3D_T_SCATTER_LEVEL_MASK, 0x7FFFFFFF);
@@ -475,10 +505,10 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
     const uint32_t runs_mask = (count == nullptr) ? (level_mask & ((1u << merge_levels) - 1u)) : 0u;
     if (runs_mask)
         hipLaunchKernelGGL(k_scatter_runs, dim3((n + kWave * kWaves - 1) / (kWave * kWaves)), dim3(kWave * kWaves), 0, st,
-                           ps, n, dout, T, runs_mask, plane_rows, n_rep, rep_stride, grad_params);
+                           ps, n, dout, T, runs_mask, plane_rows, planes_half, n_rep, rep_stride, grad_params);
     if (level_mask & ~runs_mask)
         hipLaunchKernelGGL(k_scatter, dim3((n + kTile - 1) / kTile), dim3(kWave * kWaves), 0, st, ps, n, count, dout, T,
-                           merge_levels, level_mask & ~runs_mask, plane_rows, n_rep, rep_stride, grad_params);
+                           merge_levels, level_mask & ~runs_mask, plane_rows, planes_half, n_rep, rep_stride, grad_params);
     return (int)hipGetLastError();
 }
 
@@ -659,7 +689,7 @@ __device__ __forceinline__ void emit_row(const BinPlan &plan, const GridLevel &L
 
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
-                                                             uint32_t n_rows,
+                                                             uint32_t n_rows, int planes_half,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
                                                              uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
                                                              uint32_t waves_b, BinRecord *__restrict__ arena,
@@ -701,13 +731,14 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
             // the gradient pairs are fetched three points ahead of their use (the loop is latency-bound otherwise)
             const float2 zero2 = make_float2(0.f, 0.f);
             // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
-            const float2 *prow = reinterpret_cast<const float2 *>(dplanes) + (size_t)l * plane_rows + s;
-            float2 d0 = (valid && 0 < ps.P) ? prow[0] : zero2, d1 = (valid && 1 < ps.P) ? prow[(size_t)n_rows] : zero2,
-                   d2 = (valid && 2 < ps.P) ? prow[(size_t)2 * n_rows] : zero2;
+            const size_t prow = (size_t)l * plane_rows + s;
+            float2 d0 = (valid && 0 < ps.P) ? plane_pair(dplanes, planes_half, prow) : zero2,
+                   d1 = (valid && 1 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)n_rows) : zero2,
+                   d2 = (valid && 2 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)2 * n_rows) : zero2;
             for (uint32_t p = 0; p < ps.P; ++p) {
                 const float2 d = d0;
                 d0 = d1; d1 = d2;
-                d2 = (valid && p + 3 < ps.P) ? prow[(size_t)(p + 3) * n_rows] : zero2;
+                d2 = (valid && p + 3 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)(p + 3) * n_rows) : zero2;
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
@@ -995,7 +1026,7 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
 int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
                                    uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
-                                   float *out_planes, void *stream) {
+                                   void *out_planes, int out_half, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
         (P0 < P && x2 == nullptr))
         return (int)hipErrorInvalidValue;
@@ -1013,12 +1044,12 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     per_xcd = per_xcd < cap ? per_xcd : cap;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     const float2 *tab = reinterpret_cast<const float2 *>(params);
-    float2 *out = reinterpret_cast<float2 *>(out_planes);
+    float *out = reinterpret_cast<float *>(out_planes);
     hipStream_t st = as_stream(stream);
     if (variant & 1)
-        hipLaunchKernelGGL((k_grid_encode_planes<true>), grid, block, 0, st, ps, n, tab, T, plan, out);
+        hipLaunchKernelGGL((k_grid_encode_planes<true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
     else
-        hipLaunchKernelGGL((k_grid_encode_planes<false>), grid, block, 0, st, ps, n, tab, T, plan, out);
+        hipLaunchKernelGGL((k_grid_encode_planes<false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
     return (int)hipGetLastError();
 }
 
@@ -1048,7 +1079,7 @@ size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, f
 }
 
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
-                             uint32_t P, float bound, const float *dout_planes, uint32_t n_levels,
+                             uint32_t P, float bound, const void *dout_planes_v, int dout_half, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                              void *workspace, size_t workspace_bytes, float *grad_params, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
@@ -1056,6 +1087,7 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     hipStream_t st = as_stream(stream);
+    const float *dout_planes = reinterpret_cast<const float *>(dout_planes_v);
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
@@ -1082,12 +1114,13 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
             float *rep = reinterpret_cast<float *>(workspace);
             (void)hipMemsetAsync(rep, 0, rep_bytes, st);
             const int err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, rep, st, 0xFFFFFFFFu, plane_rows,
-                                           kReplicas, (size_t)T.n_entries * 2);
+                                           kReplicas, (size_t)T.n_entries * 2, dout_half);
             hipLaunchKernelGGL(k_replica_reduce, dim3((T.n_entries * 2 + 255) / 256), dim3(256), 0, st, rep, kReplicas,
                                (size_t)T.n_entries * 2, T.n_entries * 2, grad_params);
             return err ? err : (int)hipGetLastError();
         }
-        return launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, grad_params, st, 0xFFFFFFFFu, plane_rows);
+        return launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, grad_params, st, 0xFFFFFFFFu, plane_rows, 1, 0,
+                              dout_half);
     }
     char *arena = reinterpret_cast<char *>(workspace);
     uint32_t *counts = reinterpret_cast<uint32_t *>(arena + plan.total_bytes);
@@ -1107,7 +1140,7 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
         if (fine_waves + coarse_waves)
             hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
-                               (uint32_t)s0, s1, dout_planes, plane_rows, n, T, plan, merge_levels, fine_mask, fine_waves,
+                               (uint32_t)s0, s1, dout_planes, plane_rows, n, dout_half, T, plan, merge_levels, fine_mask, fine_waves,
                                coarse_mask, coarse_waves, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * n_split), dim3(kWave * kReduceWaves), lds_reduce, st, arena,

@@ -47,7 +47,8 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     path."""
     offs, offs_p = grid_ops._offs_arg(offsets)
     P, n = offs.shape[0], x.shape[0]
-    dplanes = L.dev_f32(dplanes, "dplanes")
+    if dplanes.dtype not in (torch.float32, torch.float16) or not dplanes.is_cuda or not dplanes.is_contiguous():
+        raise L.Mi3dError("dplanes must be a contiguous float32 / float16 GPU tensor")
     if dplanes.numel() != cfg["n_levels"] * n * P * 2:
         raise L.Mi3dError(f"dplanes has {dplanes.numel()} elements, expected [L={cfg['n_levels']}][{P * n}][2]")
     grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
@@ -63,23 +64,27 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     with L.on(x):
         grid_ops._timed("scatter", lambda: L.call(
             "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
-            cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
+            int(dplanes.dtype == torch.float16), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
             L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
     return grad
 
 
 def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step=0.0):
-    """feats [L][P*n][2] and h [P*n, 4] (point-major rows)."""
+    """feats [L][P*n][2] and h [P*n, 4] (point-major rows).  Under torch.autocast(float16) the planes hold binary16
+    pairs: the first nn.Linear of the reference rounds its input to binary16 there, so the MLP output is bit-identical
+    and every pass over the planes moves half the bytes."""
     P, n = offs.shape[0], x.shape[0]
-    feats = torch.empty(cfg["n_levels"], P * n, 2, dtype=torch.float32, device=x.device)
+    pdt = torch.float16 if half_mode else torch.float32
+    feats = torch.empty(cfg["n_levels"], P * n, 2, dtype=pdt, device=x.device)
     grid_ops._timed("encode", lambda: L.call(
         "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
         cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-        L.ptr(feats), L.stream(x)), n * P)
+        L.ptr(feats), int(bool(half_mode)), L.stream(x)), n * P)
     dims = (ws[0].shape[1], ws[0].shape[0], ws[4].shape[0])
     h = torch.empty(P * n, dims[2], dtype=torch.float32, device=x.device)
     grid_ops._timed("mlp_fwd", lambda: L.call(
-        "mi3d_mlp_forward", L.ptr(feats), P * n, P * n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h),
+        "mi3d_mlp_forward", L.ptr(feats), P * n, int(bool(half_mode)), P * n, *[L.ptr(t) for t in ws], *dims,
+        int(half_mode), L.ptr(h),
         L.stream(x)), n * P)
     return feats, h, dims
 
@@ -89,10 +94,12 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
     the first P_active points of the stencil only."""
     n = x.shape[0]
     rows, plane_rows = P_active * n, feats.shape[1]
-    dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=torch.float32, device=x.device)
+    # binary16 gradient planes under autocast: what the reference's binary16 dgrad GEMM hands the encoder's backward
+    dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=feats.dtype, device=x.device)
     grads = [torch.zeros_like(t) for t in ws]
     grid_ops._timed("mlp_bwd", lambda: L.call(
-        "mi3d_mlp_backward", L.ptr(feats), plane_rows, L.ptr(dh), rows, *[L.ptr(t) for t in ws], *dims, int(half_mode),
+        "mi3d_mlp_backward", L.ptr(feats), plane_rows, int(feats.dtype == torch.float16), L.ptr(dh), rows,
+        *[L.ptr(t) for t in ws], *dims, int(half_mode),
         L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream(x)), rows)
     gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
                         n_params)

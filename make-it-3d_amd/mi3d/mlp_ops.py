@@ -23,7 +23,7 @@ class _FusedMLP(Function):
         dims = (W1.shape[1], W1.shape[0], W3.shape[0])
         with L.on(x):
             grid_ops._timed("mlp_fwd", lambda: L.call(
-                "mi3d_mlp_forward", L.ptr(x), 0, n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out),
+                "mi3d_mlp_forward", L.ptr(x), 0, 0, n, *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(out),
                 L.stream(x)), n)
         ctx.save_for_backward(x, *ws)
         ctx.meta = (dims, int(half_mode))
@@ -40,7 +40,7 @@ class _FusedMLP(Function):
         grads = [torch.zeros_like(t) for t in ws]
         with L.on(x):
             grid_ops._timed("mlp_bwd", lambda: L.call(
-                "mi3d_mlp_backward", L.ptr(x), 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
+                "mi3d_mlp_backward", L.ptr(x), 0, 0, L.ptr(dout), n, *[L.ptr(t) for t in ws], *dims, half_mode, L.ptr(dx),
                 0, *[L.ptr(g) for g in grads], L.stream(x)), n)
         return (dx, *grads, None)
 

@@ -48,7 +48,7 @@ def test_c2_full_size_march_invariants_and_gather_scatter_adjoint(cuda, oracle):
     params = torch.empty(n_params, device=cuda).uniform_(0.5, 1.0)
     feats = torch.empty(16, m * P, 2, device=cuda)
     L.call("mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), m, offs_p, int(P0), P, 1.0, L.ptr(params), 16, 16,
-           cfg["per_level_scale"], 19, 2 * 3 ** 0.5 / 1024, L.ptr(feats), L.stream())
+           cfg["per_level_scale"], 19, 2 * 3 ** 0.5 / 1024, L.ptr(feats), 0, L.stream())
     assert float(feats.min()) >= 0.5 - 1e-4 and float(feats.max()) <= 1.0 + 1e-4  # convex combinations of the table
     g = torch.empty(16, m * P, 2, device=cuda).uniform_(0.5, 1.5)
     lhs = sum(float(torch.dot(feats[l].reshape(-1).double(), g[l].reshape(-1).double())) for l in range(16))

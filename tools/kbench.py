@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--bitfield", default="dense")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
+    ap.add_argument("--half-planes", action="store_true", help="binary16 feature / gradient planes (the autocast layout)")
     a = ap.parse_args()
     what = set(a.what.split(","))
     import raymarching
@@ -64,11 +65,11 @@ def main():
     P = 13
     params = torch.empty(12196240, device=dev).uniform_(-1, 1)
     res = {"samples": n, "evals": n * P}
-    feats = torch.empty(16, P * n, 2, device=dev)
+    feats = torch.empty(16, P * n, 2, device=dev, dtype=torch.float16 if a.half_planes else torch.float32)
 
     def encode(out=feats):
         L.call("mi3d_grid_encode_points_planes", L.ptr(xs), L.ptr(xs2), n, offs_p, int(P0), P, 1.0, L.ptr(params), 16, 16,
-               cfg["per_level_scale"], 19, 2 * 3 ** 0.5 / 1024, L.ptr(out), L.stream())
+               cfg["per_level_scale"], 19, 2 * 3 ** 0.5 / 1024, L.ptr(out), int(out.dtype == torch.float16), L.stream())
 
     if "encode" in what:
         tune(T_ENCODE_VARIANT, 0)
@@ -103,15 +104,16 @@ def main():
         h = torch.empty(P * n, 4, device=dev)
 
         def fwd(rows=P * n):
-            L.call("mi3d_mlp_forward", L.ptr(feats), P * n, rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1, L.ptr(h),
-                   L.stream())
+            L.call("mi3d_mlp_forward", L.ptr(feats), P * n, int(feats.dtype == torch.float16), rows, *[L.ptr(t) for t in ws],
+                   32, 64, 4, 1, L.ptr(h), L.stream())
         res["mlp_fwd_ms"] = timeit(fwd, a.iters)
         dh = torch.randn(P * n, 4, device=dev)
-        dplanes = torch.empty(16, P * n, 2, device=dev)
+        dplanes = torch.empty(16, P * n, 2, device=dev, dtype=feats.dtype)
         grads = [torch.zeros_like(t) for t in ws]
 
         def bwd(rows=P * n):
-            L.call("mi3d_mlp_backward", L.ptr(feats), P * n, L.ptr(dh), rows, *[L.ptr(t) for t in ws], 32, 64, 4, 1,
+            L.call("mi3d_mlp_backward", L.ptr(feats), P * n, int(feats.dtype == torch.float16), L.ptr(dh), rows,
+                   *[L.ptr(t) for t in ws], 32, 64, 4, 1,
                    L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream())
         for v in (0, 1, 2):   # 0: two tiles per wave (staged), 1: one tile per wave, 2: one tile, 2 waves/SIMD (spills)
             tune(6, v)
@@ -127,10 +129,11 @@ def main():
         del dplanes, dh, h
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
-        g = torch.randn(16, P * n, 2, device=dev)
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
         res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
         g1 = g[:, :n].contiguous()
+        res["planes_dtype"] = str(feats.dtype)
         res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
         for fw in (256, 512, 768, 1024, 1536):
