@@ -215,7 +215,8 @@ def main():
     ap.add_argument("--variant-steps", type=int, default=4, help="timed steps of each non-headline variant (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-shaped", action="store_true")
-    ap.add_argument("--init-scale", type=float, default=0.25, help="GradScaler initial loss scale")
+    ap.add_argument("--init-scale", type=float, default=65536.0,
+                    help="GradScaler initial loss scale (the reference's: torch's default, nerf/utils.py:309)")
     ap.add_argument("--cpu-baseline-only", default=None, choices=["reference", "port"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -255,10 +256,11 @@ def main():
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
     # GradScaler: the reference constructs it at 65536 (nerf/utils.py:309).  On this workload the normal-smoothness
     # regulariser back-propagates through safe_normalize of finite differences that fp16 rounds to exactly zero
-    # (gradient x 1e10), so every step overflows binary16 until the scaler has halved itself down to ~1 (16 skipped
-    # steps, measured: finite at 1, overflowing at 4); a skipped step does NO optimizer work.  The bench therefore starts
-    # the scaler two halvings below where it settles (margin for the other views of a multi-GPU run - the value changes
-    # no timing) and asserts below that every timed step really applied its Adan update.
+    # (gradient x 1e10), so every step overflows binary16 until the scaler has halved itself down to ~1; a skipped step
+    # does NO optimizer work, and the loss scale decides how many binary16 gradients underflow to exact zeros (which
+    # the scatter skips - as it always did).  So the bench lets the scaler SETTLE first, exactly as a training run
+    # would: untimed steps from the reference's initial scale until several consecutive steps apply their update, and
+    # it asserts below that every timed step really applied its Adan update at that scale.
     model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"],
                                                              init_scale=args.init_scale)
     dp.broadcast_module_state(model)
@@ -332,6 +334,15 @@ def main():
         return elapsed, prof
 
     log(f"{args.workload}: timing {args.steps} steps of the headline variant {HEADLINE} on {world} GPU(s)")
+    # settle the loss scale (untimed; before the W warm-up steps of the contract)
+    settle = make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)
+    good, tries = 0, 0
+    while not render_only and opt.fp16 and good < 4 and tries < 60:
+        before = scaler.get_scale()
+        settle()
+        good = good + 1 if scaler.get_scale() >= before else 0
+        tries += 1
+    log(f"loss scale settled at {scaler.get_scale()} after {tries} untimed steps")
     elapsed, prof = run(*HEADLINE, args.steps, args.warmup)
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step")
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
@@ -405,7 +416,7 @@ def main():
             log("reference-shaped baseline (reference Python on the drop-in packages)")
             try:
                 line["reference_shaped_baseline"] = reference_shaped(model, guidance, text_z, opt, view_rays[0], wl,
-                                                                     t_fixed, dev, args.init_scale)
+                                                                     t_fixed, dev, scaler.get_scale())
             except Exception as e:
                 line["reference_shaped_baseline"] = {"value": None, "error": repr(e)}
             if line["reference_shaped_baseline"].get("value"):

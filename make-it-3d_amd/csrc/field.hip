@@ -53,6 +53,12 @@ struct F16 {
     struct KB { half8 v[2]; };
     __device__ static __forceinline__ float round(float x) { return (float)(_Float16)x; }
     __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q >> 3][q & 7] = (_Float16)x; }
+    // values 2j, 2j+1 of the K-block from a packed binary16 pair
+    __device__ static __forceinline__ void set_pair_bits(KB &k, int j, uint32_t bits) {
+        const half2v hv = __builtin_bit_cast(half2v, bits);
+        k.v[j >> 2][2 * (j & 3)] = hv[0];
+        k.v[j >> 2][2 * (j & 3) + 1] = hv[1];
+    }
     __device__ static __forceinline__ void mma(f32x16 &acc, const KB &a, const KB &b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[0], b.v[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[1], b.v[1], acc, 0, 0, 0);
@@ -139,6 +145,11 @@ struct F32 {
     struct KB { float v[16]; };
     __device__ static __forceinline__ float round(float x) { return x; }
     __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q] = x; }
+    __device__ static __forceinline__ void set_pair_bits(KB &k, int j, uint32_t bits) {  // (binary16 planes: F16 mode only)
+        const half2v hv = __builtin_bit_cast(half2v, bits);
+        k.v[2 * j] = (float)hv[0];
+        k.v[2 * j + 1] = (float)hv[1];
+    }
     __device__ static __forceinline__ void mma(f32x16 &acc, const KB &a, const KB &b) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q], b.v[q], acc, 0, 0, 0);
@@ -265,12 +276,11 @@ __device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_
                                               size_t plane_rows, float (&raw)[16], int planes_half = 0) {
     row = row < n ? row : n - 1;
     if (plane_rows != 0 && planes_half) {
+        // binary16 planes: the 8 dwords ARE the K-block (value pair j = features 2j, 2j+1 of this lane-half): they
+        // travel as bit patterns in raw[0..7] and rows_kb() re-interprets them - no conversion in either direction
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // 32 consecutive rows of one plane per load: 128 contiguous bytes per lane-half
-            const uint32_t u = reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row];
-            raw[2 * j] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu));
-            raw[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
-        }
+        for (int j = 0; j < 8; ++j)  // 32 consecutive rows of one plane per load: 128 contiguous bytes per lane-half
+            raw[j] = __uint_as_float(reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row]);
     } else if (plane_rows == 0) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
 #pragma unroll
@@ -288,8 +298,13 @@ __device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_
         }
     }
 }
-template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float (&raw)[16]) {
+template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float (&raw)[16], int planes_half = 0) {
     typename P::KB k;
+    if (planes_half) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P::set_pair_bits(k, j, __float_as_uint(raw[j]));
+        return k;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) P::set(k, q, raw[q]);
     return k;
@@ -299,7 +314,7 @@ __device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__
                                                        size_t plane_rows, int planes_half) {
     float raw[16];
     load_rows_raw(x, row, n, h, plane_rows, raw, planes_half);
-    return rows_kb<P>(raw);
+    return rows_kb<P>(raw, planes_half);
 }
 
 // [rows,4] output-side gradient as a K-block (kind X over the 4 outputs): only lane-half 0, q < 4 are non-zero
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
         for (int u = 0; u < U; ++u) {
             row[u] = ((size_t)tile + (size_t)u * n_waves) * 32 + p;
             valid[u] = row[u] < n;
-            X[u] = rows_kb<P>(raw[u]);
+            X[u] = rows_kb<P>(raw[u], planes_half);
             dO[u] = dout_kb<P>(dor[u], valid[u] && h == 0);
         }
         if (tile + U * n_waves < n_tiles) {
