@@ -342,7 +342,13 @@ def main():
         settle()
         good = good + 1 if scaler.get_scale() >= before else 0
         tries += 1
-    log(f"loss scale settled at {scaler.get_scale()} after {tries} untimed steps")
+    if not render_only and opt.fp16:
+        # two halvings of margin below the scale at which 4 consecutive steps applied: the noise of later steps (other
+        # views on other ranks, other jitter) must not overflow a timed step - GradScaler itself would sit between the
+        # two, skipping a step now and then
+        settled = scaler.get_scale()
+        scaler.update(new_scale=settled / 4.0)
+        log(f"loss scale: 4 consecutive steps applied at {settled} after {tries} untimed steps; timing at {settled / 4.0}")
     elapsed, prof = run(*HEADLINE, args.steps, args.warmup)
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step")
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}

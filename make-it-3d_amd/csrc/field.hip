@@ -276,11 +276,12 @@ __device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_
                                               size_t plane_rows, float (&raw)[16], int planes_half = 0) {
     row = row < n ? row : n - 1;
     if (plane_rows != 0 && planes_half) {
-        // binary16 planes: the 8 dwords ARE the K-block (value pair j = features 2j, 2j+1 of this lane-half): they
-        // travel as bit patterns in raw[0..7] and rows_kb() re-interprets them - no conversion in either direction
 #pragma unroll
-        for (int j = 0; j < 8; ++j)  // 32 consecutive rows of one plane per load: 128 contiguous bytes per lane-half
-            raw[j] = __uint_as_float(reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row]);
+        for (int j = 0; j < 8; ++j) {  // 32 consecutive rows of one plane per load: 128 contiguous bytes per lane-half
+            const uint32_t u = reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row];
+            raw[2 * j] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu));
+            raw[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+        }
     } else if (plane_rows == 0) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
 #pragma unroll
@@ -298,15 +299,24 @@ __device__ __forceinline__ void load_rows_raw(const float *__restrict__ x, size_
         }
     }
 }
-template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float (&raw)[16], int planes_half = 0) {
+template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float (&raw)[16]) {
     typename P::KB k;
-    if (planes_half) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) P::set_pair_bits(k, j, __float_as_uint(raw[j]));
-        return k;
-    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) P::set(k, q, raw[q]);
+    return k;
+}
+// binary16 planes: the 8 dwords a lane fetches ARE its K-block (pair j = features 2j, 2j+1 of this lane-half) - the
+// backward keeps them as bit patterns while they are in flight and re-interprets them, no conversion either way
+__device__ __forceinline__ void load_rows_half(const float *__restrict__ x, size_t row, size_t n, int h,
+                                               size_t plane_rows, uint32_t (&u)[8]) {
+    row = row < n ? row : n - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = reinterpret_cast<const uint32_t *>(x)[(size_t)(8 * h + j) * plane_rows + row];
+}
+template <class P> __device__ __forceinline__ typename P::KB rows_kb_half(const uint32_t (&u)[8]) {
+    typename P::KB k;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P::set_pair_bits(k, j, u[j]);
     return k;
 }
 template <class P>
@@ -314,7 +324,7 @@ __device__ __forceinline__ typename P::KB load_rows_kb(const float *__restrict__
                                                        size_t plane_rows, int planes_half) {
     float raw[16];
     load_rows_raw(x, row, n, h, plane_rows, raw, planes_half);
-    return rows_kb<P>(raw, planes_half);
+    return rows_kb<P>(raw);
 }
 
 // [rows,4] output-side gradient as a K-block (kind X over the 4 outputs): only lane-half 0, q < 4 are non-zero
@@ -403,9 +413,9 @@ struct Grads {
 // stage first issues the matrix products of all its (tile, output-tile) pairs step by step - consecutive MFMAs go to
 // different accumulators - and only then converts them, which gives the in-order wave four independent chains to
 // overlap (the packed converts of one accumulator run under the MFMAs of the next).
-template <class P, int U, int WPS>
+template <class P, int U, int WPS, bool HP>
 __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const float *__restrict__ x, uint32_t x_planes,
-                                                                           int planes_half, const float *__restrict__ dout,
+                                                                           int /*planes_half: HP*/, const float *__restrict__ dout,
                                                                            uint32_t n, Weights w, float *__restrict__ dx,
                                                                            uint32_t dx_planes, Grads g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -437,12 +447,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
     // the rows of the NEXT group of tiles are requested before the current group's products start and are consumed one
     // iteration later; tile u of a group is `u * n_waves` tiles further on, so every wave instruction still reads 32
     // consecutive rows
-    float raw[U][16];
+    float raw[HP ? 1 : U][16];
+    uint32_t rawh[HP ? U : 1][8];
     f32x4 dor[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const size_t r0 = ((size_t)wave + (size_t)u * n_waves) * 32 + p;
-        load_rows_raw(x, r0, n, h, x_planes, raw[u], planes_half);
+        if constexpr (HP) load_rows_half(x, r0, n, h, x_planes, rawh[u]);
+        else load_rows_raw(x, r0, n, h, x_planes, raw[u]);
         dor[u] = load_dout_raw(dout, r0, n);
     }
     for (uint32_t tile = wave; tile < n_tiles; tile += U * n_waves) {
@@ -453,14 +465,16 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
         for (int u = 0; u < U; ++u) {
             row[u] = ((size_t)tile + (size_t)u * n_waves) * 32 + p;
             valid[u] = row[u] < n;
-            X[u] = rows_kb<P>(raw[u], planes_half);
+            if constexpr (HP) X[u] = rows_kb_half<P>(rawh[u]);
+            else X[u] = rows_kb<P>(raw[u]);
             dO[u] = dout_kb<P>(dor[u], valid[u] && h == 0);
         }
         if (tile + U * n_waves < n_tiles) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t rn = ((size_t)tile + (size_t)(U + u) * n_waves) * 32 + p;
-                load_rows_raw(x, rn, n, h, x_planes, raw[u], planes_half);
+                if constexpr (HP) load_rows_half(x, rn, n, h, x_planes, rawh[u]);
+                else load_rows_raw(x, rn, n, h, x_planes, raw[u]);
                 dor[u] = load_dout_raw(dout, rn, n);
             }
         }
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
                         f32x4 o = {acc[u][4 * c], acc[u][4 * c + 1], acc[u][4 * c + 2], acc[u][4 * c + 3]};
                         __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
                     }
-                } else if (valid[u] && planes_half) {
+                } else if (valid[u] && HP) {
                     // binary16 planes: one 4-byte store per (level, row); this IS the rounding torch.autocast gives the
                     // input gradient of the first nn.Linear (a binary16 GEMM output)
 #pragma unroll
@@ -970,22 +984,20 @@ int mi3d_mlp_backward(const void *xv, uint32_t x_plane_rows, int planes_half, co
     hipStream_t st = as_stream(stream);
 #ifdef MI3D_DEV
     const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
-    if (half_mode && variant == 1) {  // one tile at a time
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
-                           dout, n, w, dx, dx_plane_rows, g);
-        return (int)hipGetLastError();
-    }
-    if (half_mode && variant == 2) {  // one tile at a time, two waves per SIMD (256 registers, spills)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 2>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
-                           dout, n, w, dx, dx_plane_rows, g);
+    if (half_mode && variant == 1 && !planes_half) {  // one tile at a time
+        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows,
+                           0, dout, n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
 #endif
-    if (half_mode)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+    if (half_mode && planes_half)
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 1,
+                           dout, n, w, dx, dx_plane_rows, g);
+    else if (half_mode)
+        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 0,
                            dout, n, w, dx, dx_plane_rows, g);
     else
-        hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, planes_half,
+        hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1, false>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, 0,
                            dout, n, w, dx, dx_plane_rows, g);
     return (int)hipGetLastError();
 }
