@@ -77,13 +77,18 @@ __device__ __forceinline__ float2 plane_pair(const float *planes, int half, size
     }
     return reinterpret_cast<const float2 *>(planes)[i];
 }
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+template <bool NT = false>
 __device__ __forceinline__ void store_plane_pair(float *planes, int half, size_t i, float a, float b) {
     if (half) {
         const uint32_t u = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)a) |
                            ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
-        reinterpret_cast<uint32_t *>(planes)[i] = u;
+        if (NT) __builtin_nontemporal_store(u, reinterpret_cast<uint32_t *>(planes) + i);
+        else reinterpret_cast<uint32_t *>(planes)[i] = u;
     } else {
-        reinterpret_cast<float2 *>(planes)[i] = make_float2(a, b);
+        f32x2_native v = {a, b};
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x2_native *>(planes) + i);
+        else reinterpret_cast<f32x2_native *>(planes)[i] = v;
     }
 }
 
@@ -154,7 +159,10 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 //   ORDER  where the pair straddles a slot, the x+1 corner still sits in the same 128-byte line 15 times out of 16;
 //          its load is issued DIRECTLY behind the slot's, so it merges with the pending miss instead of finding the
 //          line evicted again by the other 60 lanes' lines (32 KB of L1 against 64 KB of lines per point): 39.5 ->
-//          35.6 ms, saturated levels 3.8 -> 3.5 ms.
+//          35.6 ms, saturated levels 3.8 -> 3.5 ms;
+//   NT     the planes are written once and read by another kernel: stored non-temporally they stop evicting the
+//          level's 4 MB table from the XCD's 4 MB L2 (FETCH_SIZE showed 41 GB of table re-fetches per launch against
+//          49 MB of tables): 34.6 -> 30.4 ms with binary16 planes (loading the positions non-temporally as well: no change).
 // Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
 // per CU (+2-6 ms); evaluating the stencil three points at a time with the +-eps x-neighbours adjacent and all 24 loads
 // in flight (35.6 -> 36.0 ms: the coarse levels lose to the lower occupancy what the fine ones gain); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the
@@ -201,7 +209,7 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
     }
 }
 
-template <bool PAIR>
+template <bool PAIR, bool NT>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
                                                                        EncodePlan plan, float *__restrict__ planes,
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                 float r0 = 0.f, r1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
-                store_plane_pair(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
+                store_plane_pair<NT>(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
             }
         }
     }
@@ -1036,7 +1044,7 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
     const uint32_t tiles = (n + kTile - 1) / kTile;
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 1);
+    const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 3);
     const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
     uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
     const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
@@ -1046,10 +1054,12 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const float2 *tab = reinterpret_cast<const float2 *>(params);
     float *out = reinterpret_cast<float *>(out_planes);
     hipStream_t st = as_stream(stream);
-    if (variant & 1)
-        hipLaunchKernelGGL((k_grid_encode_planes<true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+    if ((variant & 3) == 3)
+        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+    else if (variant & 1)
+        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
     else
-        hipLaunchKernelGGL((k_grid_encode_planes<false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
     return (int)hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ extern "C" int mi3d_dev_tunable[32];
 
 // indices
 enum : int {
-    MI3D_T_ENCODE_VARIANT = 0,     // bit 0: 16-byte pair loads
+    MI3D_T_ENCODE_VARIANT = 0,     // bit 0: 16-byte pair loads, bit 1 (with bit 0): non-temporal plane stores
     MI3D_T_ENCODE_WGS_PER_CU = 1,
     MI3D_T_ENCODE_ONLY_LEVEL = 2,  // >= 0: the plan holds this level alone (per-level timing)
     MI3D_T_EMIT_FINE_WAVES = 3,

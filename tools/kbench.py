@@ -75,20 +75,20 @@ def main():
         tune(T_ENCODE_VARIANT, 0)
         encode()
         ref = feats.clone()
-        for v in (0, 1):
+        for v in (0, 1, 3):
             tune(T_ENCODE_VARIANT, v)
             feats.zero_()
             ms = timeit(encode, a.iters)
             res[f"encode_variant{v}_ms"] = ms
             res[f"encode_variant{v}_bitexact"] = bool(torch.equal(feats, ref))
         del ref
-        tune(T_ENCODE_VARIANT, 1)
+        tune(T_ENCODE_VARIANT, -1)
         for w in (2, 3, 4, 6):
             tune(T_ENCODE_WGS, w)
-            res[f"encode_v1_wgs{w}_ms"] = timeit(encode, a.iters)
+            res[f"encode_wgs{w}_ms"] = timeit(encode, a.iters)
         tune(T_ENCODE_WGS, -1)
     if "levels" in what:
-        for v in (1,):
+        for v in (3,):
             tune(T_ENCODE_VARIANT, v)
             per = []
             for l in range(16):
