@@ -547,6 +547,12 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         1536: 114.0, 2048: 114.3, 3072: 115.6, 4096: 118.2).
 //                         On levels whose cells are longer than a marching step, equal-cell RUNS of consecutive
 //                         lanes are summed first (through an LDS slab, see k_scatter_runs) and emit one record set.
+//                         Measured and rejected for the fine levels: staging the 16-byte records in per-(wave, bin)
+//                         LDS rings and copying them out as whole 64-byte pieces (16 per store instruction instead
+//                         of ~40 scattered lane-stores) - the slot counter, ring write, ready check and copy are ~9
+//                         dependent LDS operations per 64 records and cost what the stores did (dense random
+//                         gradients 76 -> 84 ms; a real step 100 -> 103 ms); walking the levels in the outer loop so
+//                         that only one level's region lines are open at a time (76 -> 79 ms).
 //   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS in
 //                         64-bit fixed point (LDS fp32 atomics retire 0.38 lanes/clk/CU, 64-bit integer ones 5.3:
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
