@@ -376,8 +376,8 @@ def main():
                     "algorithmic_work_per_launch": work / n_launch, "note": note}
 
         roofs = [
-            roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, cell "
-                 "reuse; csrc/hashgrid.hip)", "encode", ENCODE_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS, "GB/s",
+            roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, "
+                 "non-temporal plane stores; csrc/hashgrid.hip)", "encode", ENCODE_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS, "GB/s",
                  "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
                  "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
                  "k_grid_encode_planes"),
@@ -387,10 +387,10 @@ def main():
                  "SDS pass reaches stencil point 0 only (1/13 of the evaluations), the regulariser pass all 13",
                  "scatter_binned"),
             roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
-                 "HBM-streaming bound: 144 B read + 16 B written per evaluation", "k_mlp_forward"),
+                 "streams 64 B of binary16 planes in + 16 B out per evaluation (fp32 planes without autocast: 128 B)", "k_mlp_forward"),
             roof("k_mlp_backward<F16> (recompute + dgrad + wgrad, both orientations, next tile prefetched)", "mlp_bwd",
                  25600.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
-                 "144 B read + 128 B written per evaluation; 67 MFMAs per 32 rows", "k_mlp_backward"),
+                 "80 B read + 64 B written per evaluation with binary16 planes; 67 MFMAs per 32 rows", "k_mlp_backward"),
         ]
         roofs.sort(key=lambda r: -r["ms_per_step"])
         line = {
@@ -401,7 +401,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 hash grid (fp32 gather, fp32 gradient contributions accumulated in 64-bit fixed point) + f16 "
-                     "MFMA MLP (torch.autocast semantics), f16 U-Net",
+                     "MFMA MLP (torch.autocast semantics; the planes between gather, MLP and scatter hold the binary16 "
+                     "values autocast rounds them to), f16 U-Net",
             "data": "synthetic (reference orbit rays, random-init weights, analytic occupancy)",
             "config": {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
                                    f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step (t={T_FIXED}: the SDS "
