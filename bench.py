@@ -268,7 +268,7 @@ def main():
     guidance = sd_standin.StableDiffusionStandIn(dev)
     text_z = guidance.get_text_embeds()
     view_rays = [R.view_rays(wl["H"], wl["W"], view=rank * views + v, device=dev) for v in range(views)]
-    t_fixed = torch.tensor([T_FIXED], dtype=torch.long, device=dev)
+    t_fixed = T_FIXED  # an int: the guidance decides its branch on the host without a device sync
     torch.manual_seed(1234 + rank)
 
     render_only = wl.get("mode") == "render"
@@ -457,7 +457,7 @@ def bench_refine(args, wl, dev, rank, world):
                                  betas=(0.9, 0.99), eps=1e-15)
     guidance = sd_standin.StableDiffusionStandIn(dev)
     text_z = guidance.get_text_embeds()
-    t_fixed = torch.tensor([T_FIXED], dtype=torch.long, device=dev)
+    t_fixed = T_FIXED  # an int: the guidance decides its branch on the host without a device sync
     w2c = torch.linalg.inv(R.orbit_pose(1.25, 80.0, 30.0 + 45.0 * rank, device=dev)[0])
     focal = 1.0 / (2 * np.tan(np.radians(20) / 2))
     radius = wl["radius_px"] / H * 2.0

@@ -7,7 +7,13 @@ stock PyTorch-ROCm.  This module rebuilds the two networks the SDS branch touche
 head dim 64, linear transformer projections, GroupNorm 32, time embedding 1280) and the VAE encoder
 (`AutoencoderKL` encoder: 128/256/512/512, 2 res-blocks per level, mid attention, 8 moment channels) - layer for
 layer from memory [PARITY UNPINNED: shapes/FLOPs faithful, numerics meaningless with random weights], and restates
-`StableDiffusion.train_step`'s SDS branch (nerf/sd.py:117-151,163-172) and `encode_imgs` (:212-220).
+`StableDiffusion.train_step` (nerf/sd.py:117-174) with BOTH of its branches and `encode_imgs` / `decode_latents`
+(:201-220): the SDS branch (:160-172), and - for t/1000 <= 0.4 on a view that is not `is_large` - the denoise + CLIP
+branch (:153-159): one DDIM step to t-1 (diffusers `DDIMScheduler.step`, eta 0, epsilon prediction, restated from its
+published formula), VAE decode, CLIP image-image and image-text similarity.  That branch runs under no_grad in the
+reference (decode_latents :203) - it yields a loss VALUE and the denoised image, no gradient - so it is forward work
+only; its networks (`VAEDecoderSD`, `CLIPStandIn` = ViT-B/16 as nerf/utils.py:248 loads it) are shape-faithful
+random-weight stand-ins like the rest.
 """
 import math
 
@@ -168,17 +174,123 @@ class VAEEncoderSD(nn.Module):
         return self.quant_conv(self.conv_out(F.silu(self.norm_out(h))))  # [B, 8, H/8, W/8] = (mean, logvar)
 
 
+class VAEDecoderSD(nn.Module):
+    """`AutoencoderKL` decoder: post_quant 4->4, conv_in 4->512, mid (res, attention, res), up blocks 512/512/256/128
+    with 3 res-blocks each and a nearest-x2 + conv upsampler between them, GroupNorm + SiLU + conv_out -> 3."""
+
+    def __init__(self, ch=(512, 512, 256, 128), layers=3):
+        super().__init__()
+        self.post_quant_conv = nn.Conv2d(4, 4, 1)
+        c = ch[0]
+        self.conv_in = nn.Conv2d(4, c, 3, padding=1)
+        self.mid1, self.mid2 = ResBlock(c, c, None, eps=1e-6), ResBlock(c, c, None, eps=1e-6)
+        self.mid_norm, self.mid_attn = nn.GroupNorm(32, c, eps=1e-6), Attention(c, c, 1)
+        blocks = []
+        for lvl, co in enumerate(ch):
+            for _ in range(layers):
+                blocks.append(ResBlock(c, co, None, eps=1e-6))
+                c = co
+            if lvl < len(ch) - 1:
+                blocks.append(nn.Conv2d(c, c, 3, padding=1))  # after nearest x2
+        self.blocks = nn.ModuleList(blocks)
+        self.norm_out, self.conv_out = nn.GroupNorm(32, c, eps=1e-6), nn.Conv2d(c, 3, 3, padding=1)
+
+    def forward(self, z):
+        h = self.mid1(self.conv_in(self.post_quant_conv(z)))
+        B, C, H, W = h.shape
+        a = self.mid_attn(self.mid_norm(h).permute(0, 2, 3, 1).reshape(B, H * W, C))
+        h = self.mid2(h + a.reshape(B, H, W, C).permute(0, 3, 1, 2))
+        for b in self.blocks:
+            h = b(F.interpolate(h, scale_factor=2.0, mode="nearest")) if isinstance(b, nn.Conv2d) else b(h)
+        return self.conv_out(F.silu(self.norm_out(h)))
+
+
+class _ClipBlock(nn.Module):
+    def __init__(self, width, heads):
+        super().__init__()
+        self.ln_1, self.attn = nn.LayerNorm(width), nn.MultiheadAttention(width, heads, batch_first=True)
+        self.ln_2 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential(nn.Linear(width, width * 4), nn.GELU(), nn.Linear(width * 4, width))
+
+    def forward(self, x, mask=None):
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False, attn_mask=mask)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class CLIPStandIn(nn.Module):
+    """OpenAI CLIP ViT-B/16 (`clip.load("ViT-B/16")`, nerf/utils.py:248): vision tower 224 px / patch 16 / width 768 /
+    12 layers / 12 heads, text tower context 77 / width 512 / 12 layers / 8 heads / vocabulary 49408, joint dimension
+    512.  `encode_image`, `encode_text` as the reference calls them; `tokenize` stands in for clip.tokenize (hashes the
+    prompt's bytes into token ids - there is no BPE vocabulary offline)."""
+
+    def __init__(self, image_size=224, patch=16, width=768, layers=12, heads=12, embed=512, ctx=77, vocab=49408,
+                 text_width=512, text_layers=12, text_heads=8):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width, patch, stride=patch, bias=False)
+        n_tok = (image_size // patch) ** 2 + 1
+        self.class_embedding = nn.Parameter(torch.randn(width) * width ** -0.5)
+        self.positional_embedding_v = nn.Parameter(torch.randn(n_tok, width) * width ** -0.5)
+        self.ln_pre, self.ln_post = nn.LayerNorm(width), nn.LayerNorm(width)
+        self.visual = nn.ModuleList([_ClipBlock(width, heads) for _ in range(layers)])
+        self.proj = nn.Parameter(torch.randn(width, embed) * width ** -0.5)
+        self.ctx = ctx
+        self.token_embedding = nn.Embedding(vocab, text_width)
+        self.positional_embedding_t = nn.Parameter(torch.randn(ctx, text_width) * 0.01)
+        self.text = nn.ModuleList([_ClipBlock(text_width, text_heads) for _ in range(text_layers)])
+        self.ln_final = nn.LayerNorm(text_width)
+        self.text_projection = nn.Parameter(torch.randn(text_width, embed) * text_width ** -0.5)
+        self.register_buffer("causal", torch.full((ctx, ctx), float("-inf")).triu_(1), persistent=False)
+
+    def encode_image(self, image):
+        x = self.conv1(image.to(self.conv1.weight.dtype)).flatten(2).transpose(1, 2)
+        x = torch.cat([self.class_embedding.expand(x.shape[0], 1, -1), x], 1) + self.positional_embedding_v
+        x = self.ln_pre(x)
+        for blk in self.visual:
+            x = blk(x)
+        return self.ln_post(x[:, 0]) @ self.proj
+
+    def tokenize(self, prompts):
+        prompts = [prompts] if isinstance(prompts, str) else prompts
+        out = torch.zeros(len(prompts), self.ctx, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            ids = [49406] + [1 + (b * 193 + j * 7) % 49000 for j, b in enumerate(p.encode()[: self.ctx - 2])] + [49407]
+            out[i, : len(ids)] = torch.tensor(ids)
+        return out
+
+    def encode_text(self, tokens):
+        x = self.token_embedding(tokens) + self.positional_embedding_t
+        for blk in self.text:
+            x = blk(x, self.causal.to(x.dtype))
+        x = self.ln_final(x)
+        return x[torch.arange(x.shape[0]), tokens.argmax(-1)] @ self.text_projection  # the end-of-text token's state
+
+
+def ddim_step(alphas_cumprod, noise_pred, t, sample):
+    """diffusers DDIMScheduler.step after set_timesteps(num_train_timesteps) (sd.py:154-155): eta 0, epsilon
+    prediction, no sample clipping, set_alpha_to_one False (the Stable-Diffusion scheduler config) - one step from t to
+    t - 1:  x0 = (x_t - sqrt(1 - a_t) eps) / sqrt(a_t);  x_{t-1} = sqrt(a_{t-1}) x0 + sqrt(1 - a_{t-1}) eps."""
+    a_t = alphas_cumprod[t].view(-1, 1, 1, 1)
+    prev = t - 1
+    a_prev = torch.where(prev >= 0, alphas_cumprod[prev.clamp(min=0)], alphas_cumprod[0]).view(-1, 1, 1, 1)
+    x0 = (sample - (1 - a_t).sqrt() * noise_pred) / a_t.sqrt()
+    return a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * noise_pred
+
+
 class StableDiffusionStandIn(nn.Module):
     """`StableDiffusion` surface used by the coarse stage: `train_step(text_embeddings, pred_rgb, ...)`."""
 
-    def __init__(self, device, step_range=(0.2, 0.6), dtype=torch.float16, seed=0):
+    def __init__(self, device, step_range=(0.2, 0.6), dtype=torch.float16, seed=0, with_decoder=False,
+                 unet_kw=None, vae_kw=None, decoder_kw=None):
         super().__init__()
         self.device = device
         g = torch.random.fork_rng(devices=[])
         with g:
             torch.manual_seed(seed)
-            self.unet = UNetSD2()
-            self.vae_encoder = VAEEncoderSD()
+            self.unet = UNetSD2(**(unet_kw or {}))
+            self.vae_encoder = VAEEncoderSD(**(vae_kw or {}))
+            # only the denoise + CLIP branch (t <= 400, sd.py:153) decodes; the SDS benchmark never builds it
+            self.vae_decoder = VAEDecoderSD(**(decoder_kw or {})) if with_decoder else None
         self.to(device)
         self.unet.to(dtype)  # frozen, weights kept in half like an inference deployment; VAE stays fp32 (has grad)
         for p in self.parameters():
@@ -200,11 +312,44 @@ class StableDiffusionStandIn(nn.Module):
         std = torch.exp(0.5 * logvar.clamp(-30, 20))
         return (mean + std * torch.randn_like(mean)) * 0.18215
 
-    def sds_gradient(self, text_embeddings, pred_rgb, guidance_scale=10, t=None):
-        """Returns (latents [1,4,64,64] with graph, grad [1,4,64,64]) - sd.py:124-151,163-170."""
+    def decode_latents(self, latents):
+        """sd.py:201-209 (no_grad, as there)."""
+        if self.vae_decoder is None:
+            raise RuntimeError("construct StableDiffusionStandIn(with_decoder=True) for the denoise + CLIP branch")
+        with torch.no_grad():
+            imgs = self.vae_decoder((1 / 0.18215 * latents).to(self.vae_decoder.conv_in.weight.dtype)).float()
+        return (imgs / 2 + 0.5).clamp(0, 1)
+
+    def aug(self, rgb):
+        """sd.py:49-52: Resize((224, 224)) + CLIP normalisation."""
+        x = F.interpolate(rgb, (224, 224), mode="bilinear", align_corners=False, antialias=True)
+        mean = torch.tensor((0.48145466, 0.4578275, 0.40821073), device=rgb.device).view(1, 3, 1, 1)
+        std = torch.tensor((0.26862954, 0.26130258, 0.27577711), device=rgb.device).view(1, 3, 1, 1)
+        return (x - mean) / std
+
+    def img_clip_loss(self, clip_model, rgb1, rgb2):
+        """sd.py:97-104."""
+        z1, z2 = clip_model.encode_image(self.aug(rgb1)), clip_model.encode_image(self.aug(rgb2))
+        z1, z2 = z1 / z1.norm(dim=-1, keepdim=True), z2 / z2.norm(dim=-1, keepdim=True)
+        return -(z1 * z2).sum(-1).mean()
+
+    def img_text_clip_loss(self, clip_model, rgb, prompt):
+        """sd.py:106-114."""
+        z1 = clip_model.encode_image(self.aug(rgb))
+        z1 = z1 / z1.norm(dim=-1, keepdim=True)
+        zt = clip_model.encode_text(clip_model.tokenize(prompt).to(self.device))
+        zt = zt / zt.norm(dim=-1, keepdim=True)
+        return -(z1 * zt).sum(-1).mean()
+
+    def _predict_noise(self, text_embeddings, pred_rgb, guidance_scale, t):
+        """sd.py:124-151: 512 x 512 resize, VAE encode (with graph), noise, U-Net on the CFG pair, guidance."""
         pred_rgb_512 = F.interpolate(pred_rgb, (512, 512), mode="bilinear", align_corners=False)
+        # the branch rule (sd.py:153) needs t on the host; the reference draws it on the device and pays a sync in the
+        # `if` - drawn on the host here (or passed in as an int) there is none
         if t is None:
-            t = torch.randint(self.min_step, self.max_step + 1, [1], dtype=torch.long, device=self.device)
+            t = int(torch.randint(self.min_step, self.max_step + 1, [1]).item())
+        t_host = int(t) if not torch.is_tensor(t) else int(t.item())
+        t = torch.tensor([t_host], dtype=torch.long, device=self.device)
         latents = self.encode_imgs(pred_rgb_512)
         with torch.no_grad():
             noise = torch.randn_like(latents)
@@ -214,12 +359,32 @@ class StableDiffusionStandIn(nn.Module):
                             encoder_hidden_states=text_embeddings.to(self.unet.conv_in.weight.dtype)).float()
             eps_uncond, eps_text = eps.chunk(2)
             eps = eps_text + guidance_scale * (eps_text - eps_uncond)  # sic: anchored on eps_text (sd.py:151)
+        return latents, noise, noisy, eps, t, t_host
+
+    def sds_gradient(self, text_embeddings, pred_rgb, guidance_scale=10, t=None):
+        """Returns (latents [1,4,64,64] with graph, grad [1,4,64,64]) - sd.py:124-151,163-170."""
+        latents, noise, _, eps, t, _ = self._predict_noise(text_embeddings, pred_rgb, guidance_scale, t)
+        with torch.no_grad():
             grad = torch.nan_to_num((1 - self.alphas[t]) * (eps - noise))
         return latents, grad
 
     def train_step(self, text_embeddings, pred_rgb, ref_rgb=None, noise=None, islarge=False, ref_text=None,
                    clip_model=None, guidance_scale=10, t=None):
-        """SDS branch of sd.py:117-174: injects the gradient with latents.backward(retain_graph=True)."""
-        latents, grad = self.sds_gradient(text_embeddings, pred_rgb, guidance_scale, t)
+        """sd.py:117-174.  t/1000 <= 0.4 on a view that is not `islarge`: one DDIM step, decode, CLIP similarities ->
+        (loss value, denoised image), nothing is back-propagated (the reference decodes under no_grad).  Otherwise the
+        SDS branch: injects the gradient with latents.backward(retain_graph=True) and returns (0, None).
+        `t` (an int, or a [1] long tensor) overrides the random draw - benchmarks pin the branch with it."""
+        latents, noise, noisy, eps, t, t_host = self._predict_noise(text_embeddings, pred_rgb, guidance_scale, t)
+        if not islarge and t_host / self.num_train_timesteps <= 0.4:
+            if clip_model is None or ref_rgb is None or ref_text is None:
+                raise ValueError("the denoise + CLIP branch (t <= 400) needs clip_model, ref_rgb and ref_text")
+            with torch.no_grad():
+                de_latents = ddim_step(self.alphas, eps, t, noisy)
+            imgs = self.decode_latents(de_latents)
+            loss = 10 * self.img_clip_loss(clip_model, imgs, ref_rgb) + \
+                10 * self.img_text_clip_loss(clip_model, imgs, ref_text)
+            return loss, imgs
+        with torch.no_grad():
+            grad = torch.nan_to_num((1 - self.alphas[t]) * (eps - noise))
         latents.backward(gradient=grad, retain_graph=True)
         return 0, None

@@ -72,7 +72,7 @@ def _captured_grads(cuda, mode, **opt_over):
     try:
         torch.manual_seed(5)
         sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt,
-                                sds_backward=mode, t=torch.tensor([400], device=cuda))
+                                sds_backward=mode, t=500)  # > 400: the SDS branch (sd.py:153)
     finally:
         torch.nn.utils.clip_grad_norm_ = orig
     return captured
@@ -151,3 +151,22 @@ def test_fused_adan_kernel_matches_the_torch_op_sequence(cuda):
         for p, q in zip(ref_p, fus_p):
             for k in ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad"):
                 assert torch.allclose(a.state[p][k], b.state[q][k], rtol=2e-5, atol=1e-8), k
+
+
+@pytest.mark.gpu
+def test_denoise_clip_branch_full_size_networks(cuda):
+    """The t <= 400 branch of the guidance (nerf/sd.py:153-159) with the full-size VAE decoder and ViT-B/16 stand-ins
+    (the U-Net shrunk: it is exercised at full size by bench.py): forward work only, nothing reaches the render."""
+    from mi3d import sd_standin as S
+    g = S.StableDiffusionStandIn(cuda, with_decoder=True, unet_kw=dict(ch=(64, 128, 128, 128), ctx_dim=1024))
+    clip = S.CLIPStandIn().to(cuda).half()
+    assert sum(p.numel() for p in clip.parameters()) > 140e6          # ViT-B/16 + text tower: ~150 M parameters
+    assert sum(p.numel() for p in g.vae_decoder.parameters()) > 45e6  # the SD VAE decoder: ~49 M
+    rgb = torch.rand(1, 3, 128, 128, device=cuda, requires_grad=True)
+    ref = torch.rand(1, 3, 512, 512, device=cuda)
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss, imgs = g.train_step(g.get_text_embeds(), rgb * 1.0, ref_rgb=ref, ref_text="a toy", clip_model=clip, t=300)
+    assert imgs.shape == (1, 3, 512, 512) and torch.isfinite(imgs).all()
+    assert torch.isfinite(loss) and not loss.requires_grad and rgb.grad is None
+    loss, imgs = g.train_step(g.get_text_embeds(), rgb * 1.0, ref_rgb=ref, ref_text="a toy", clip_model=clip, t=450)
+    assert loss == 0 and imgs is None and rgb.grad is not None
