@@ -400,17 +400,27 @@ def main():
             "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 hash grid (fp32 gather, fp32 gradient contributions accumulated in 64-bit fixed point) + f16 "
-                     "MFMA MLP (torch.autocast semantics; the planes between gather, MLP and scatter hold the binary16 "
-                     "values autocast rounds them to), f16 U-Net",
+            "dtype": ("f32 hash grid + f16 MFMA MLP (torch.autocast semantics)" if render_only else
+                      "f32 hash grid (fp32 gather, fp32 gradient contributions accumulated in 64-bit fixed point) + f16 "
+                      "MFMA MLP (torch.autocast semantics; the planes between gather, MLP and scatter hold the binary16 "
+                      "values autocast rounds them to), f16 U-Net"),
             "data": "synthetic (reference orbit rays, random-init weights, analytic occupancy)",
-            "config": {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
-                                   f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step (t={T_FIXED}: the SDS "
-                                   f"branch of nerf/sd.py:153), occupancy {wl['bitfield']}, {m} samples/view x 13 "
-                                   f"field evaluations, {views} view(s) per step",
-                       "views_per_step": world * views, "sds_backward": HEADLINE[1], "gradient_records": HEADLINE[0],
-                       "optimizer_steps_applied": args.steps * views, "grad_scaler_scale": scaler.get_scale(),
-                       "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad all-reduce)"},
+            "config": ({"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, L=16 hash "
+                                    f"grid + 3x64 MLP, forward render only (no diffusion, no backward), occupancy "
+                                    f"{wl['bitfield']}, {m} samples in the last view x 7 field evaluations, {views} "
+                                    f"view(s) per step",
+                        "views_per_step": world * views,
+                        "rays_per_s": world * views * wl["H"] * wl["W"] * args.steps / elapsed,
+                        "samples_per_s": world * sum(evals.get("encode", [])) / 7.0 / elapsed,
+                        "parallelism": f"dp{world} (independent views)"} if render_only else
+                       {"workload": f"{args.workload}: {wl['H']}x{wl['W']} rays, max_steps {wl['max_steps']}, "
+                                    f"L=16 hash grid + 3x64 MLP, SD2-base-shaped U-Net SDS step (t={T_FIXED}: the SDS "
+                                    f"branch of nerf/sd.py:153), occupancy {wl['bitfield']}, {m} samples/view x 13 "
+                                    f"field evaluations, {views} view(s) per step",
+                        "views_per_step": world * views, "sds_backward": HEADLINE[1], "gradient_records": HEADLINE[0],
+                        "optimizer_steps_applied": args.steps * views, "grad_scaler_scale": scaler.get_scale(),
+                        "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad "
+                                       f"all-reduce)"}),
             "variants_ms_per_step": variants,
             "roofline": roofs[0],
             "rooflines_other": roofs[1:],
