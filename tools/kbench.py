@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--bitfield", default="dense")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
     ap.add_argument("--half-planes", action="store_true", help="binary16 feature / gradient planes (the autocast layout)")
+    ap.add_argument("--dev", default="", help="tunables set before anything runs, e.g. 10=1,3=2048 (csrc/mi3d_dev.h)")
     a = ap.parse_args()
     what = set(a.what.split(","))
     import raymarching
@@ -47,6 +48,8 @@ def main():
 
     def tune(i, v):
         lib.mi3d_dev_set(i, v)
+    for kv in filter(None, a.dev.split(",")):
+        tune(*map(int, kv.split("=")))
     dev = torch.device("cuda:0")
     cfg = dict(n_levels=16, base_resolution=16, per_level_scale=1.3819128274917603, log2_hashmap_size=19)
     model = network.NeRFNetwork(sds_step.make_opt()).to(dev)
@@ -127,6 +130,11 @@ def main():
         res["mlp_bwd_TFLOPs"] = P * n * 25600.0 / res["mlp_bwd_ms"] / 1e9
         res["mlp_bwd_stream_TBps"] = P * n * (128 + 16 + 128) / res["mlp_bwd_ms"] / 1e9
         del dplanes, dh, h
+    if "scatter13" in what:  # the 13-point scatter alone, as configured (--dev): for rocprofv3 --kernel-trace --stats
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
+            xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240), a.iters)
+        del g
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
@@ -136,7 +144,7 @@ def main():
         res["planes_dtype"] = str(feats.dtype)
         res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
-        for fw in (256, 512, 768, 1024, 1536):
+        for fw in (768, 1024, 1536, 2048, 3072):
             tune(T_EMIT_FINE, fw)
             res[f"scatter_fp32_P13_fine_waves{fw}_ms"] = timeit(lambda: field_ops.scatter_binned(
                 xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
