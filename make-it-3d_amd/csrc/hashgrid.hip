@@ -559,6 +559,7 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
 constexpr uint32_t kEmitWavesMax = 1536;
+constexpr uint32_t kReduceWavesC = 16;  // waves of a reduce workgroup (= kReduceWaves below)
 
 struct __attribute__((packed, aligned(4))) BinRecord {
     uint32_t entry;  // level-local entry index
@@ -585,6 +586,9 @@ struct BinPlan {
     uint32_t level_max0[MI3D_MAX_LEVELS];   // first entry of the level in level_max[]; inside: [wave]
     uint64_t total_bytes;
     uint32_t row_mask;                      // fine fp32 levels stored as 16-byte x-pair records (RowRecord)
+    uint32_t level_split[MI3D_MAX_LEVELS];  // reduce workgroups that share one bin of the level
+    uint32_t level_wg0[MI3D_MAX_LEVELS];    // first reduce workgroup of the level; inside: [bin][split]
+    uint32_t n_reduce_wgs;
     uint32_t total_counts, total_max;
     uint32_t n_levels, n_bins;
 };
@@ -641,6 +645,33 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
     }
     return p;
 }
+// How many reduce workgroups share a bin.  A bin's records are spread over the level's emitting waves, so `split`
+// workgroups can each take every split-th group of 16 regions.  The bins are NOT equally heavy: a fine level puts ~4.4 M
+// x-pair records into each of its 64 bins at C2, but level 0 is ONE bin that receives 80 M run-merged records, level 1
+// two bins with 54 M each (tools/scatter_fill.py) - with the same split for every bin the reduce waited 12 ms for those
+// few workgroups.  So the split follows the expected work per bin (region capacity x waves x the usual fill; an x-pair
+// record costs two single ones), normalised so that the average bin gets `base_split` workgroups.
+inline void plan_reduce_splits(BinPlan &p, const GridTable &T, uint32_t base_split) {
+    double work[MI3D_MAX_LEVELS], total = 0.0;
+    uint32_t bins_total = 0;
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        const bool row = (p.row_mask >> l) & 1u;
+        work[l] = (double)p.level_waves[l] * p.level_cap[l] * (row ? 0.78 * 2.0 : 0.4);
+        total += work[l] * level_bins(T.level[l]);
+        bins_total += level_bins(T.level[l]);
+    }
+    const double target = total / bins_total / base_split;  // work one reduce workgroup should get
+    p.n_reduce_wgs = 0;
+    for (uint32_t l = 0; l < T.n_levels; ++l) {
+        uint32_t split = (uint32_t)(work[l] / target + 0.5);
+        const uint32_t most = p.level_waves[l] / kReduceWavesC ? p.level_waves[l] / kReduceWavesC : 1u;  // >= 1 region per wave
+        split = split < 1u ? 1u : (split > most ? most : split);
+        p.level_split[l] = split;
+        p.level_wg0[l] = p.n_reduce_wgs;
+        p.n_reduce_wgs += level_bins(T.level[l]) * split;
+    }
+}
+
 inline size_t bin_workspace_bytes(const BinPlan &p) {
     return (size_t)p.total_bytes + (size_t)p.total_counts * sizeof(uint32_t) +
            (size_t)p.total_max * sizeof(float);
@@ -665,48 +696,13 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
     }
 }
 
-// the x-pair of one (y, z) corner of one point as ONE RowRecord (see the struct); e0 / e1: entries of the x and x + 1 corner
-__device__ __forceinline__ void emit_row(const BinPlan &plan, const GridLevel &L, uint32_t l, uint32_t gw, uint32_t e0,
-                                         uint32_t e1, uint32_t t, float a, float b, float fx, uint32_t *fill,
-                                         char *__restrict__ arena, float *__restrict__ grad_table, float &lmax) {
-    const float gx = 1.0f - fx;
-    const bool finite = fabsf(a) <= 3.4028234663852886e38f && fabsf(b) <= 3.4028234663852886e38f;
-    lmax = finite ? fmaxf(lmax, fmaxf(fabsf(a), fabsf(b))) : __builtin_inff();  // |contribution| <= max(|a|, |b|)
-    const uint32_t cap = plan.level_cap[l], bins = level_bins(L);
-    RowRecord *base = reinterpret_cast<RowRecord *>(arena + plan.level_base[l]);
-    auto append = [&](uint32_t e, uint32_t tt, float va, float vb, float vfx) {
-        const uint32_t bin = e >> kBinShift;
-        const uint32_t slot = atomicAdd(&fill[plan.level_bin0[l] + bin], 1u);  // wave-private LDS counter
-        if (slot < cap) {
-            base[((size_t)gw * bins + bin) * cap + slot] = RowRecord{e | (tt << kRowEntryBits), va, vb, vfx};
-            return true;
-        }
-        return false;
-    };
-    if ((e0 >> kBinShift) == (e1 >> kBinShift)) {
-        if (append(e0, t, a, b, fx)) return;
-    } else {  // the pair straddles two bins: two singles (fx = 0: only the header's entry receives (a, b))
-        const bool ok0 = append(e0, 0u, gx * a, gx * b, 0.f), ok1 = append(e1, 0u, fx * a, fx * b, 0.f);
-        if (ok0 && ok1) return;
-        if (ok0 || ok1) {  // one of them went to its region: the other straight to the table
-            float *dst = grad_table + ((size_t)L.offset + (ok0 ? e1 : e0)) * 2;
-            const float w = ok0 ? fx : gx;
-            unsafeAtomicAdd(dst, w * a); unsafeAtomicAdd(dst + 1, w * b);
-            return;
-        }
-    }
-    // region full: straight to the table
-    float *d0 = grad_table + ((size_t)L.offset + e0) * 2, *d1 = grad_table + ((size_t)L.offset + e1) * 2;
-    unsafeAtomicAdd(d0, gx * a); unsafeAtomicAdd(d0 + 1, gx * b);
-    unsafeAtomicAdd(d1, fx * a); unsafeAtomicAdd(d1 + 1, fx * b);
-}
-
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
                                                              uint32_t n_rows, int planes_half,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
                                                              uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
-                                                             uint32_t waves_b, BinRecord *__restrict__ arena,
+                                                             uint32_t waves_b, uint32_t fine_level_major,
+                                                             BinRecord *__restrict__ arena,
                                                              uint32_t *__restrict__ counts,
                                                              float *__restrict__ level_max,
                                                              float *__restrict__ grad_table) {
@@ -732,27 +728,75 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
     if (gw >= n_waves) return;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
-    for (uint32_t s0 = s_begin + gw * kWave; s0 < s_end; s0 += n_waves * kWave) {
-        const uint32_t s = s0 + lane;
-        const bool valid = s < s_end;
-        float base[2][3];
-        load_bases(ps, s, valid, base);
-        for (uint32_t l = 0; l < T.n_levels; ++l) {
-            if (!((level_mask >> l) & 1u)) continue;
+    // The (tile, level) pairs of this wave, in one of two orders.  Tile-major (coarse role): the positions of a tile are
+    // loaded once for all its levels.  Level-major (fine role): the wave appends to the 64 regions of ONE level at a time,
+    // so the lines it has open - 1536 waves x 64 bins x 128 B = 12.6 MB against 100 MB with all eight fine levels open -
+    // stay in the L2s until they are full; partially written lines that get evicted cost the store path 2.4x
+    // (tools/store_bench.hip, profiles/store_bench_r02.txt: 184 G vs 75 G scattered 16-byte records per second).
+    const uint32_t nl = (uint32_t)__popc(level_mask);
+    const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
+    const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
+    const bool level_major = !role_b && fine_level_major;
+    uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
+    bool valid = false;
+    float b00 = 0.f, b01 = 0.f, b02 = 0.f, b10 = 0.f, b11 = 0.f, b12 = 0.f;  // the tile's positions
+    for (uint32_t it = 0; it < nl * nt; ++it) {
+        const uint32_t ti = level_major ? it % nt : it / nl, li = level_major ? it / nt : it % nl;
+        uint32_t rest = level_mask;
+        for (uint32_t k = 0; k < li; ++k) rest &= rest - 1u;
+        const uint32_t l = (uint32_t)__builtin_ctz(rest);  // the li-th level of the role's mask
+        if (ti != cur_tile) {
+            cur_tile = ti;
+            s = first + ti * span + lane;
+            valid = s < s_end;
+            float fresh[2][3];
+            load_bases(ps, s, valid, fresh);
+            b00 = fresh[0][0]; b01 = fresh[0][1]; b02 = fresh[0][2];
+            b10 = fresh[1][0]; b11 = fresh[1][1]; b12 = fresh[1][2];
+        }
+        {
+            const float base[2][3] = {{b00, b01, b02}, {b10, b11, b12}};
             const GridLevel L = T.level[l];
             const bool merge = l < merge_levels;
             float lmax = 0.f;
-            // the gradient pairs are fetched three points ahead of their use (the loop is latency-bound otherwise)
-            const float2 zero2 = make_float2(0.f, 0.f);
+            // wave-uniform, hoisted out of the point loop: the level's region capacity, this wave's counters and regions
+            const uint32_t cap = plan.level_cap[l];
+            uint32_t *fill_l = fill + plan.level_bin0[l];
+            RowRecord *region0 = reinterpret_cast<RowRecord *>(reinterpret_cast<char *>(arena) + plan.level_base[l]) +
+                                 (size_t)gw * level_bins(L) * cap;
+            // ALL gradient pairs of this (tile, level) are fetched before its first record is stored.  gfx950 has one
+            // counter for vector loads and stores (vmcnt), and the compiler cannot count the conditional stores between a
+            // load and its use - so a load consumed inside the point loop costs "s_waitcnt vmcnt(0)": a full drain of the
+            // wave's scattered stores, once per point (that was the emit's bound: ~4 us per point).  Up front it is one
+            // drain per 13 points; the pairs wait in registers as raw bits and are picked by a select chain (p is uniform).
             // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
-            const size_t prow = (size_t)l * plane_rows + s;
-            float2 d0 = (valid && 0 < ps.P) ? plane_pair(dplanes, planes_half, prow) : zero2,
-                   d1 = (valid && 1 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)n_rows) : zero2,
-                   d2 = (valid && 2 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)2 * n_rows) : zero2;
+            // (unconditional loads from clamped rows - a predicated load makes the compiler wait for it on the spot; what
+            // an invalid lane or a point >= P fetched is never looked at)
+            const size_t prow = (size_t)l * plane_rows + (valid ? s : s_end - 1u);
+            uint32_t raw0[kMaxPts], raw1[kMaxPts];
+            if (planes_half) {
+#pragma unroll
+                for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
+                    const uint32_t kc = k < ps.P ? k : ps.P - 1u;
+                    raw0[k] = reinterpret_cast<const uint32_t *>(dplanes)[prow + (size_t)kc * n_rows];
+                    raw1[k] = 0u;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
+                    const uint32_t kc = k < ps.P ? k : ps.P - 1u;
+                    const uint2 v = reinterpret_cast<const uint2 *>(dplanes)[prow + (size_t)kc * n_rows];
+                    raw0[k] = v.x; raw1[k] = v.y;
+                }
+            }
             for (uint32_t p = 0; p < ps.P; ++p) {
-                const float2 d = d0;
-                d0 = d1; d1 = d2;
-                d2 = (valid && p + 3 < ps.P) ? plane_pair(dplanes, planes_half, prow + (size_t)(p + 3) * n_rows) : zero2;
+                uint32_t r0 = raw0[0], r1 = raw1[0];
+#pragma unroll
+                for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[k] : r1; }
+                const float2 d = planes_half
+                    ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
+                                  (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
+                    : make_float2(__uint_as_float(r0), __uint_as_float(r1));
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
@@ -767,16 +811,51 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
                 const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
                 if (!merge && ((plan.row_mask >> l) & 1u)) {  // fine level, one 16-byte record per x-corner pair
+                    // This path is bound by instruction issue, not by the store path (tools/store_bench.hip: the same
+                    // appends run 2x faster without the arithmetic around them), so it is written for few instructions:
+                    // two integer multiplies per point instead of sixteen (the +1 neighbours of a hash term differ by
+                    // the prime), the x + 1 entry derived from the x entry, the level's maximum taken from the gradient
+                    // pair (every contribution is a weight <= 1 times it), a 32-bit index into this wave's regions.
                     if (has) {
-                        // t: e1 = e0 ^ (2^t - 1) on a hashed level (the bits a +1 carry flips in cx), 0 = dense "+1"
-                        const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~cx) + 1u : 0u;
+                        const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
+                        lmax = finite ? fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y))) : __builtin_inff();  // inf / NaN -> inf
                         const float wyz[4] = {gy * gz, fy * gz, gy * fz, fy * fz};
+                        auto put = [&](uint32_t e, uint32_t tt, float va, float vb, float vfx) {
+                            const uint32_t bin = e >> kBinShift;
+                            const uint32_t slot = atomicAdd(&fill_l[bin], 1u);  // wave-private LDS counter
+                            if (slot < cap) {
+                                region0[__umul24(bin, cap) + slot] = RowRecord{e | (tt << kRowEntryBits), va, vb, vfx};
+                                return true;
+                            }
+                            return false;
+                        };
+                        auto to_table = [&](uint32_t e, float va, float vb) {  // region full: straight to the table
+                            float *dst = grad_table + ((size_t)L.offset + e) * 2;
+                            unsafeAtomicAdd(dst, va); unsafeAtomicAdd(dst + 1, vb);
+                        };
+                        // hashed (2^k entries): e(x + 1) = e(x) ^ flip, flip = the bits a +1 carry changes in cx, and
+                        // t = their count goes into the record so that the reduce can do the same; dense: t = 0, "+1"
+                        const uint32_t mask = L.size - 1u;
+                        const uint32_t flip = (cx ^ (cx + 1u)) & mask;
+                        const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~cx) + 1u : 0u;
+                        const uint32_t hy0 = cy * kPrimeY, hy1 = hy0 + kPrimeY, hz0 = cz * kPrimeZ, hz1 = hz0 + kPrimeZ;
 #pragma unroll
                         for (uint32_t j = 0; j < 4; ++j) {
-                            const uint32_t e0 = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
-                            const uint32_t e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
-                            emit_row(plan, L, l, gw, e0, e1, t, wyz[j] * d.x, wyz[j] * d.y, fx, fill,
-                                     reinterpret_cast<char *>(arena), grad_table, lmax);
+                            uint32_t e0, e1;
+                            if (L.hashed) {
+                                e0 = (cx ^ ((j & 1u) ? hy1 : hy0) ^ ((j >> 1) ? hz1 : hz0)) & mask;
+                                e1 = e0 ^ flip;
+                            } else {
+                                e0 = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
+                                e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
+                            }
+                            const float a = wyz[j] * d.x, b = wyz[j] * d.y;
+                            if ((e0 >> kBinShift) == (e1 >> kBinShift)) {
+                                if (!put(e0, t, a, b, fx)) { to_table(e0, gx * a, gx * b); to_table(e1, fx * a, fx * b); }
+                            } else {  // the pair straddles two bins: two singles (fx = 0: only the header's entry receives (a, b))
+                                if (!put(e0, 0u, gx * a, gx * b, 0.f)) to_table(e0, gx * a, gx * b);
+                                if (!put(e1, 0u, fx * a, fx * b, 0.f)) to_table(e1, fx * a, fx * b);
+                            }
                         }
                     }
                     continue;
@@ -846,7 +925,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
         level_max[plan.level_max0[lane] + gw] = lmax_all[wave_in_wg][lane];
 }
 
-constexpr int kReduceWaves = 16;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
+constexpr int kReduceWaves = (int)kReduceWavesC;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
 
 // A level that received a non-finite gradient: every entry of the bin becomes NaN, so that torch's GradScaler (and
 // anyone reading encoder.params.grad) sees the overflow exactly as it would after the reference's float atomics.
@@ -872,21 +951,21 @@ __device__ __forceinline__ unsigned long long fixed_point(float x) {
 __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *__restrict__ arena,
                                                                      const uint32_t *__restrict__ counts,
                                                                      const float *__restrict__ level_max, GridTable T,
-                                                                     BinPlan plan, uint32_t n_split,
-                                                                     float *__restrict__ grad_table) {
+                                                                     BinPlan plan, float *__restrict__ grad_table) {
     extern __shared__ unsigned long long acc[];  // [2][kBinEntries]: feature-major, so one atomic instruction's 64
     // addresses spread over every 8-byte bank pair (entry-major pairs would leave half of them unused per instruction)
     __shared__ float wg_max[kReduceWaves];
-    // n_split workgroups share a bin (each takes every n_split-th group of emitting waves): 4 for a full-size pass, 1 for
-    // a small one (the point-0 pass of the SDS backward), where zeroing and flushing the 128 KB tile is most of the work
-    const uint32_t b = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    // level_split[l] workgroups share a bin of level l (each takes every split-th group of emitting waves), see
+    // plan_reduce_splits; a small pass (the point-0 pass of the SDS backward) gets fewer: zeroing and flushing the 128 KB
+    // tile is most of its work
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = threadIdx.x / kWave;
-    uint32_t lvl = 0;  // which level does this bin belong to?  (uniform scan of at most 16 entries)
+    uint32_t lvl = 0;  // which level does this workgroup belong to?  (uniform scan of at most 16 entries)
     for (uint32_t l = 0; l < T.n_levels; ++l)
-        if (plan.level_bin0[l] <= b) lvl = l;
+        if (plan.level_wg0[l] <= blockIdx.x) lvl = l;
+    const uint32_t n_split = plan.level_split[lvl];
+    const uint32_t lb = (blockIdx.x - plan.level_wg0[lvl]) / n_split, split = (blockIdx.x - plan.level_wg0[lvl]) % n_split;
     const uint32_t cap = plan.level_cap[lvl], n_waves = plan.level_waves[lvl], bins = level_bins(T.level[lvl]);
-    const uint32_t lb = b - plan.level_bin0[lvl];
     for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += blockDim.x) acc[i] = 0ull;
     const bool row = (plan.row_mask >> lvl) & 1u;
     float scale;
@@ -913,7 +992,8 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     bool any = false;
     constexpr uint32_t U = 8;  // records in flight per lane
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
-        const uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
+        uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
+        cnt = cnt < cap ? cnt : cap;
         if (row) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
             const GridLevel &L = T.level[lvl];
@@ -1157,21 +1237,47 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                               (int)lds_reduce);
     // the fine levels (>= merge_levels) and the coarse ones are two roles of one emit launch
     const uint32_t all = (uint32_t)((1ull << T.n_levels) - 1);
-    const uint32_t coarse_mask = merge_levels ? (all & ((1u << merge_levels) - 1u)) : 0u;
-    const uint32_t fine_mask = all & ~coarse_mask;
+    uint32_t coarse_mask = merge_levels ? (all & ((1u << merge_levels) - 1u)) : 0u;
+    const uint32_t dev_mask = (uint32_t)MI3D_TUNE(MI3D_T_SCATTER_LEVEL_MASK, 0x7FFFFFFF);  // per-role timing (dev build)
+    const uint32_t coarse_mask_all = coarse_mask;
+    const uint32_t fine_mask = all & ~coarse_mask_all & dev_mask;
+    coarse_mask &= dev_mask;
     const uint32_t fine_waves = fine_mask ? plan.level_waves[__builtin_ctz(fine_mask)] : 0u;
     const uint32_t coarse_waves = coarse_mask ? plan.level_waves[__builtin_ctz(coarse_mask)] : 0u;
+    const uint32_t emit_order = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_ORDER, 0);
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
         if (fine_waves + coarse_waves)
             hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
                                (uint32_t)s0, s1, dout_planes, plane_rows, n, dout_half, T, plan, merge_levels, fine_mask, fine_waves,
-                               coarse_mask, coarse_waves, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
+                               coarse_mask, coarse_waves, emit_order, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
-        hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_bins * n_split), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
-                           counts, level_max, T, plan, n_split, grad_params);
+        plan_reduce_splits(plan, T, n_split);
+        hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_reduce_wgs), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
+                           counts, level_max, T, plan, grad_params);
     }
     return (int)hipGetLastError();
 }
+
+
+#ifdef MI3D_DEV
+// development build only (tools/bin/libmi3d_dev.so): the record-arena plan of one slice, for tools/ scripts that look
+// at region fill.  out[0] = arena bytes, out[1] = counters, out[2] = merge levels, then per level: bins, cap, waves,
+// first counter, row flag.
+void mi3d_dev_scatter_plan(uint32_t n_slice, uint32_t P, float bound, float step, uint32_t n_levels,
+                           uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                           unsigned long long *out) {
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
+    const uint32_t merge_levels = default_merge_levels(T, step01 * (3.0f / 1.05f));
+    const BinPlan p = plan_for(T, n_slice, P, step01, merge_levels);
+    out[0] = p.total_bytes; out[1] = p.total_counts; out[2] = merge_levels;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        out[3 + 5 * l] = level_bins(T.level[l]); out[4 + 5 * l] = p.level_cap[l]; out[5 + 5 * l] = p.level_waves[l];
+        out[6 + 5 * l] = p.level_cnt0[l]; out[7 + 5 * l] = (p.row_mask >> l) & 1u;
+    }
+}
+#endif
 
 }  // extern "C"

@@ -144,11 +144,14 @@ def main():
         res["planes_dtype"] = str(feats.dtype)
         res["scatter_fp32_P1_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, None, offs[:1], 1, 1.0, g1, cfg, step, 12196240), a.iters)
-        for fw in (768, 1024, 1536, 2048, 3072):
-            tune(T_EMIT_FINE, fw)
-            res[f"scatter_fp32_P13_fine_waves{fw}_ms"] = timeit(lambda: field_ops.scatter_binned(
-                xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
+        for order in (0, 1):  # csrc/mi3d_dev.h MI3D_T_EMIT_ORDER: the fine role tile-major / level-major
+            tune(10, order)
+            for fw in (768, 1024, 1536, 2048, 3072):
+                tune(T_EMIT_FINE, fw)
+                res[f"scatter_fp32_P13_order{order}_fine_waves{fw}_ms"] = timeit(lambda: field_ops.scatter_binned(
+                    xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
         tune(T_EMIT_FINE, -1)
+        tune(10, -1)
     print(json.dumps(res, indent=1))
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
