@@ -545,14 +545,19 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         gradients: 256 waves 175 ms, 512: 110, 768: 89, 1024: 79, 1536: 80, 2048: 86, 4096: 94; with
 //                         the gradients of a real step - whole iteration of tools/field_bench.py - 768: 130, 1024: 118.5,
 //                         1536: 114.0, 2048: 114.3, 3072: 115.6, 4096: 118.2).
-//                         On levels whose cells are longer than a marching step, equal-cell RUNS of consecutive
-//                         lanes are summed first (through an LDS slab, see k_scatter_runs) and emit one record set.
-//                         Measured and rejected for the fine levels: staging the 16-byte records in per-(wave, bin)
-//                         LDS rings and copying them out as whole 64-byte pieces (16 per store instruction instead
-//                         of ~40 scattered lane-stores) - the slot counter, ring write, ready check and copy are ~9
-//                         dependent LDS operations per 64 records and cost what the stores did (dense random
-//                         gradients 76 -> 84 ms; a real step 100 -> 103 ms); walking the levels in the outer loop so
-//                         that only one level's region lines are open at a time (76 -> 79 ms).
+//                         On the coarse levels (cells of 3 marching steps and more) a wave first SUMS what its
+//                         tile contributes - in registers across the stencil points that share their base position's
+//                         cell, then in a 512-slot LDS hash table across lanes - and emits one record per distinct
+//                         entry: 0.10 G records per 70 M evaluations where per-point run merging left 1.66 G
+//                         (tools/scatter_fill.py), which had made the coarse levels the larger half of both passes.
+//                         What the profile showed on the way (rocprofv3 on tools/kbench.py --what scatter13, dev
+//                         level mask): the emit is insensitive to the store pattern (LDS-staged 64-byte pieces:
+//                         76 -> 84 ms; level-major order, one level's region lines open at a time: 76 -> 79 ms;
+//                         tools/store_bench.hip gives the store path alone 75-184 G records/s, the emit runs at 95),
+//                         to a 3x shorter instruction stream on the fine path (-1 ms) and to the per-point
+//                         "s_waitcnt vmcnt(0)" drains (gfx950 counts loads and stores in one counter; all pairs of
+//                         a (tile, level) are now fetched up front) - because the coarse role, not the fine one, was
+//                         the long pole: fine levels alone 13.5 ms per slice, coarse alone 15.0, together 24.8.
 //   pass 2 (k_bin_reduce) one workgroup per (bin, split) streams the bin's records and accumulates them in LDS in
 //                         64-bit fixed point (LDS fp32 atomics retire 0.38 lanes/clk/CU, 64-bit integer ones 5.3:
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
@@ -569,7 +574,7 @@ struct __attribute__((packed, aligned(4))) BinRecord {
 // one - (1 - fx) (a, b) for the corner at x, fx (a, b) for the one at x + 1, with (a, b) = w_y w_z (dfeature0, dfeature1)
 // - and the two entries differ in their low bits only (hashed: e1 = e0 ^ (2^t - 1), t = 1 + trailing ones of cx, because x
 // enters the hash with prime 1; dense: e1 = e0 + 1), so 16 bytes carry what two 12-byte records did: half the
-// lane-stores of the emit (its bound: one scattered lane-store per clock per CU) and two thirds of the bytes.
+// lane-stores and LDS counter updates of the emit and two thirds of the bytes.
 // hdr = e0 | t << 19 (t = 0: dense "+1").  fx == 0 marks a single (only e0 receives (a, b)): pairs that straddle a bin.
 struct __attribute__((aligned(16))) RowRecord {
     uint32_t hdr;
@@ -649,14 +654,15 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
 // workgroups can each take every split-th group of 16 regions.  The bins are NOT equally heavy: a fine level puts ~4.4 M
 // x-pair records into each of its 64 bins at C2, but level 0 is ONE bin that receives 80 M run-merged records, level 1
 // two bins with 54 M each (tools/scatter_fill.py) - with the same split for every bin the reduce waited 12 ms for those
-// few workgroups.  So the split follows the expected work per bin (region capacity x waves x the usual fill; an x-pair
-// record costs two single ones), normalised so that the average bin gets `base_split` workgroups.
-inline void plan_reduce_splits(BinPlan &p, const GridTable &T, uint32_t base_split) {
+// few workgroups.  So the split follows the expected work per bin (region capacity x waves x the usual fill - 0.78 for
+// per-point records, a few per cent for the gathered records of the coarse levels, whose regions are sized for the worst
+// case; an x-pair record costs two single ones), normalised so that the average bin gets `base_split` workgroups.
+inline void plan_reduce_splits(BinPlan &p, const GridTable &T, uint32_t base_split, uint32_t merge_levels) {
     double work[MI3D_MAX_LEVELS], total = 0.0;
     uint32_t bins_total = 0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         const bool row = (p.row_mask >> l) & 1u;
-        work[l] = (double)p.level_waves[l] * p.level_cap[l] * (row ? 0.78 * 2.0 : 0.4);
+        work[l] = (double)p.level_waves[l] * p.level_cap[l] * (row ? 0.78 * 2.0 : (l < merge_levels ? 0.05 : 0.78));
         total += work[l] * level_bins(T.level[l]);
         bins_total += level_bins(T.level[l]);
     }
@@ -696,6 +702,26 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
     }
 }
 
+// round-to-nearest-even of x (|x| < 2^51) as a 64-bit two's complement integer: adding 1.5 * 2^52 in binary64 leaves it in
+// the low mantissa bits.  Same result as __float2ll_rn, 5 VALU operations instead of the ~13 of the software conversion
+// (there is no native float -> int64), four times per record.
+__device__ __forceinline__ unsigned long long fixed_point(float x) {
+    const double d = (double)x + 6755399441055744.0;
+    return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
+}
+
+// Coarse levels (cells of 3 marching steps and more): the 64 samples of a tile x 13 stencil points x 8 corners fall on a
+// few hundred distinct entries at most, so the wave first sums them in a small LDS hash table - entry -> two 64-bit
+// fixed-point sums, scaled by a power of two from the tile's largest gradient - and then emits ONE record per distinct
+// entry.  (Round 1-2 summed equal-cell runs of consecutive lanes per stencil point through an LDS slab: 7x fewer records
+// than contributions on level 0, 1.6x on level 7 - 1.66 G records per slice at C2, more than the fine levels', and a
+// handful of bins to reduce them in.  This merges across lanes, runs AND stencil points.)  A contribution that finds no
+// slot within kMergeProbes goes out as a record of its own.
+constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t emit_wave_words(uint32_t n_bins) {  // 32-bit words of LDS per emitting wave (even)
+    return 4u * kMergeSlots + kMergeSlots + ((n_bins + 1u) & ~1u);
+}
+
 __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
                                                              uint32_t n_rows, int planes_half,
@@ -706,10 +732,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                                                              uint32_t *__restrict__ counts,
                                                              float *__restrict__ level_max,
                                                              float *__restrict__ grad_table) {
-    extern __shared__ uint32_t fill_all[];  // [kWaves][n_bins] records appended so far by this wave
-    __shared__ float slab_all[kWaves][kWave * kRunStride];
-    __shared__ uint32_t cell_all[kWaves][kWave * 3];
-    __shared__ uint32_t start_all[kWaves][kWave + 1];
+    extern __shared__ unsigned long long emit_lds[];  // per wave: gather-table sums, its keys, the region counters
     __shared__ float lmax_all[kWaves][MI3D_MAX_LEVELS];
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -720,13 +743,13 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
     const bool role_b = gw >= waves_a;
     if (role_b) gw -= waves_a;
     const uint32_t level_mask = role_b ? mask_b : mask_a, n_waves = role_b ? waves_b : waves_a;
-    uint32_t *fill = fill_all + wave_in_wg * plan.n_bins;
-    float *slab = slab_all[wave_in_wg];
-    uint32_t *cells = cell_all[wave_in_wg], *starts = start_all[wave_in_wg];
+    unsigned long long *sums = emit_lds + (size_t)wave_in_wg * (emit_wave_words(plan.n_bins) / 2u);  // [kMergeSlots][2]
+    uint32_t *keys = reinterpret_cast<uint32_t *>(sums + 2 * kMergeSlots);                            // [kMergeSlots]
+    uint32_t *fill = keys + kMergeSlots;  // [n_bins] records appended so far by this wave
     for (uint32_t b = lane; b < plan.n_bins; b += kWave) fill[b] = 0;
+    for (uint32_t i = lane; i < kMergeSlots; i += kWave) { keys[i] = kMergeEmpty; sums[2 * i] = 0ull; sums[2 * i + 1] = 0ull; }
     if (lane < MI3D_MAX_LEVELS) lmax_all[wave_in_wg][lane] = 0.f;
     if (gw >= n_waves) return;
-    const unsigned long long lt = (1ull << lane) - 1ull;
 
     // The (tile, level) pairs of this wave, in one of two orders.  Tile-major (coarse role): the positions of a tile are
     // loaded once for all its levels.  Level-major (fine role): the wave appends to the 64 regions of ONE level at a time,
@@ -789,7 +812,89 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     raw0[k] = v.x; raw1[k] = v.y;
                 }
             }
+            // coarse level: the power-of-two scale of the wave's gather table, from the tile's largest gradient (every
+            // contribution is a weight <= 1 times a gradient, 6656 of them per tile: |sum| < 2^13 2^40)
+            float merge_scale = 0.f;
+            double merge_unscale = 0.0;
+            bool merge_any = false, dead = false;
+            if (merge) {
+                float tmax = 0.f;
+                bool bad = false;
+#pragma unroll
+                for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
+                    const float dx = planes_half ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] & 0xFFFFu))
+                                                 : __uint_as_float(raw0[k]);
+                    const float dy = planes_half ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] >> 16))
+                                                 : __uint_as_float(raw1[k]);
+                    if (valid && k < ps.P) {
+                        bad |= !(fabsf(dx) <= 3.4028234663852886e38f && fabsf(dy) <= 3.4028234663852886e38f);
+                        tmax = fmaxf(tmax, fmaxf(fabsf(dx), fabsf(dy)));
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+                if (__ballot(bad) != 0ull) {  // inf / NaN in the tile: the level is poisoned by the reduce, nothing to sum
+                    lmax = __builtin_inff();
+                    dead = true;
+                } else if (tmax > 0.f) {
+                    int ex;
+                    (void)frexpf(tmax, &ex);  // tmax < 2^ex
+                    int k2 = 40 - ex;
+                    k2 = k2 > 126 ? 126 : (k2 < -126 ? -126 : k2);
+                    merge_scale = ldexpf(1.0f, k2);
+                    merge_unscale = ldexp(1.0, -k2);
+                    merge_any = true;
+                }
+            }
+            uint32_t bx = 0, by = 0, bz = 0;  // the cell of the current group's base position
+            float acc0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool acc_any = false;
+            auto gather = [&](uint32_t e, float g0, float g1) {  // (e, g0, g1) into the wave's gather table (kMergeSlots)
+                uint32_t slot = (e * 2654435761u) >> (32 - 9);
+                static_assert(kMergeSlots == 512, "the slot hash keeps 9 bits");
+                bool placed = false;
+                for (uint32_t tries = 0; tries < kMergeProbes; ++tries) {
+                    const uint32_t old = atomicCAS(&keys[slot], kMergeEmpty, e);
+                    if (old == kMergeEmpty || old == e) { placed = true; break; }
+                    slot = (slot + 1u) & (kMergeSlots - 1u);
+                }
+                if (placed) {
+                    atomicAdd(&sums[2 * slot], fixed_point(g0 * merge_scale));
+                    atomicAdd(&sums[2 * slot + 1], fixed_point(g1 * merge_scale));
+                } else {
+                    emit_record(plan, L, l, gw, e, g0, g1, fill, arena, grad_table, lmax);
+                }
+            };
+            auto flush_group = [&]() {
+                if (acc_any) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) {
+                        if (acc0[k] != 0.f || acc1[k] != 0.f)
+                            gather(grid_entry(L, bx + (k & 1u), by + ((k >> 1) & 1u), bz + (k >> 2)), acc0[k], acc1[k]);
+                        acc0[k] = 0.f; acc1[k] = 0.f;
+                    }
+                }
+                acc_any = false;
+            };
             for (uint32_t p = 0; p < ps.P; ++p) {
+                if (merge && (p == 0u || p == ps.P0)) {  // a new group of stencil points: around x, then around x2
+                    flush_group();
+                    float qb[3];
+                    const int which = p < ps.P0 ? 0 : 1;
+#pragma unroll
+                    for (int dd = 0; dd < 3; ++dd) {
+                        if (ps.mode == 0) {
+                            qb[dd] = base[which][dd];
+                        } else {
+                            const float w = clampf(base[which][dd], -ps.bound, ps.bound);
+                            qb[dd] = (w + ps.bound) / (2.0f * ps.bound);
+                        }
+                    }
+                    float unused;
+                    grid_cell(qb[0], L.scale, bx, unused);
+                    grid_cell(qb[1], L.scale, by, unused);
+                    grid_cell(qb[2], L.scale, bz, unused);
+                }
                 uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
                 for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[k] : r1; }
@@ -797,7 +902,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                   (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                     : make_float2(__uint_as_float(r0), __uint_as_float(r1));
-                const bool has = valid && (d.x != 0.f || d.y != 0.f);
+                const bool has = valid && !dead && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
                 float q[3];
@@ -811,9 +916,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
                 const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
                 if (!merge && ((plan.row_mask >> l) & 1u)) {  // fine level, one 16-byte record per x-corner pair
-                    // This path is bound by instruction issue, not by the store path (tools/store_bench.hip: the same
-                    // appends run 2x faster without the arithmetic around them), so it is written for few instructions:
-                    // two integer multiplies per point instead of sixteen (the +1 neighbours of a hash term differ by
+                    // Written for few instructions: two integer multiplies per point instead of sixteen (the +1 neighbours of a hash term differ by
                     // the prime), the x + 1 entry derived from the x entry, the level's maximum taken from the gradient
                     // pair (every contribution is a weight <= 1 times it), a 32-bit index into this wave's regions.
                     if (has) {
@@ -872,38 +975,30 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     }
                     continue;
                 }
-                // coarse level: sum equal-cell runs of consecutive lanes through the slab (see k_scatter_runs)
+                // coarse level: the stencil points of one base position mostly share its cell - those are summed in
+                // registers first (acc0 / acc1, flushed when the group ends); the others go to the gather table directly
+                const bool same = has && cx == bx && cy == by && cz == bz;
+                if (same) {
+                    acc_any = true;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    slab[lane * kRunStride + 2 * k] = has ? wk[k] * d.x : 0.f;
-                    slab[lane * kRunStride + 2 * k + 1] = has ? wk[k] * d.y : 0.f;
+                    for (uint32_t k = 0; k < 8; ++k) { acc0[k] += wk[k] * d.x; acc1[k] += wk[k] * d.y; }
+                } else if (has) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k)
+                        gather(grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2)), wk[k] * d.x, wk[k] * d.y);
                 }
-                cells[lane * 3] = cx; cells[lane * 3 + 1] = cy; cells[lane * 3 + 2] = cz;
-                const uint32_t px = __shfl_up(cx, 1, 64), py = __shfl_up(cy, 1, 64), pz = __shfl_up(cz, 1, 64);
-                const bool prev_has = (lane > 0) && ((act >> (lane - 1)) & 1ull);
-                const bool head = has && !(prev_has && px == cx && py == cy && pz == cz);
-                const unsigned long long heads = __ballot(head);
-                const uint32_t n_runs = (uint32_t)__popcll(heads);
-                if (head) starts[__popcll(heads & lt)] = (uint32_t)lane;
+            }
+            if (merge) flush_group();
+            if (merge && merge_any) {  // one record per distinct entry the tile touched on this level; the table is left empty
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t i = lane & 15u, rs = lane >> 4;
-                for (uint32_t r0 = 0; r0 < n_runs; r0 += 4) {
-                    const uint32_t r = r0 + rs;
-                    float sum = 0.f;
-                    uint32_t first = 0;
-                    if (r < n_runs) {
-                        first = starts[r];
-                        const unsigned long long stop = (~act | heads) & ~((2ull << first) - 1ull);
-                        const uint32_t end = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
-                        for (uint32_t j = first; j < end; ++j) sum += slab[j * kRunStride + i];
-                    }
-                    const float other = __shfl_xor(sum, 1, 64);  // feature 1 of the same corner (all lanes take part)
-                    if (r < n_runs && (i & 1u) == 0u) {
-                        const uint32_t k = i >> 1;
-                        const uint32_t e = grid_entry(L, cells[first * 3] + (k & 1u), cells[first * 3 + 1] + ((k >> 1) & 1u),
-                                                      cells[first * 3 + 2] + (k >> 2));
-                        if (sum != 0.f || other != 0.f)
-                            emit_record(plan, L, l, gw, e, sum, other, fill, arena, grad_table, lmax);
+                for (uint32_t i = lane; i < kMergeSlots; i += kWave) {
+                    const uint32_t e = keys[i];
+                    if (e != kMergeEmpty) {
+                        const long long a0 = (long long)sums[2 * i], a1 = (long long)sums[2 * i + 1];
+                        keys[i] = kMergeEmpty; sums[2 * i] = 0ull; sums[2 * i + 1] = 0ull;
+                        if (a0 != 0 || a1 != 0)
+                            emit_record(plan, L, l, gw, e, (float)((double)a0 * merge_unscale), (float)((double)a1 * merge_unscale),
+                                        fill, arena, grad_table, lmax);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -934,14 +1029,6 @@ __device__ __forceinline__ void poison_bin(const GridLevel &L, uint32_t lb, floa
     const uint32_t live = L.size - e0 < kBinEntries ? L.size - e0 : kBinEntries;
     float *dst = grad_table + ((size_t)L.offset + e0) * 2;
     for (uint32_t i = threadIdx.x; i < live * 2; i += blockDim.x) dst[i] = __builtin_nanf("");
-}
-
-// round-to-nearest-even of x (|x| < 2^51) as a 64-bit two's complement integer: adding 1.5 * 2^52 in binary64 leaves it in
-// the low mantissa bits.  Same result as __float2ll_rn, 5 VALU operations instead of the ~13 of the software conversion
-// (there is no native float -> int64), four times per record.
-__device__ __forceinline__ unsigned long long fixed_point(float x) {
-    const double d = (double)x + 6755399441055744.0;
-    return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
 }
 
 // Every record value is scaled by a power of two 2^k chosen from the largest |value| any wave emitted for the level
@@ -1230,7 +1317,9 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     char *arena = reinterpret_cast<char *>(workspace);
     uint32_t *counts = reinterpret_cast<uint32_t *>(arena + plan.total_bytes);
     float *level_max = reinterpret_cast<float *>(counts + plan.total_counts);
-    const size_t lds = (size_t)kWaves * plan.n_bins * sizeof(uint32_t);
+    const size_t lds = (size_t)kWaves * emit_wave_words(plan.n_bins) * sizeof(uint32_t);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const size_t lds_reduce = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
     // per call: the attribute is per device and the call is a host-side table write (no static, re-entrant)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1252,7 +1341,7 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                                (uint32_t)s0, s1, dout_planes, plane_rows, n, dout_half, T, plan, merge_levels, fine_mask, fine_waves,
                                coarse_mask, coarse_waves, emit_order, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
-        plan_reduce_splits(plan, T, n_split);
+        plan_reduce_splits(plan, T, n_split, merge_levels);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_reduce_wgs), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
                            counts, level_max, T, plan, grad_params);
     }
