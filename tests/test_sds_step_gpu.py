@@ -160,6 +160,8 @@ def test_denoise_clip_branch_full_size_networks(cuda):
     from mi3d import sd_standin as S
     g = S.StableDiffusionStandIn(cuda, with_decoder=True, unet_kw=dict(ch=(64, 128, 128, 128), ctx_dim=1024))
     clip = S.CLIPStandIn().to(cuda).half()
+    for prm in clip.parameters():
+        prm.requires_grad_(False)  # frozen, as the guidance networks are
     assert sum(p.numel() for p in clip.parameters()) > 140e6          # ViT-B/16 + text tower: ~150 M parameters
     assert sum(p.numel() for p in g.vae_decoder.parameters()) > 45e6  # the SD VAE decoder: ~49 M
     rgb = torch.rand(1, 3, 128, 128, device=cuda, requires_grad=True)
