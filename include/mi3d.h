@@ -177,9 +177,9 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
                              uint32_t log2_hashmap_size, float step, float *grad_params, void *stream);
 
-/* The same scatter without global atomics: every corner contribution (equal-cell runs of neighbouring samples
- * summed first on the coarse levels; the two x-neighbours of a corner pair as ONE 16-byte record on the fine levels)
- * is appended to the region of its 64-KB gradient bin, then each bin is accumulated in LDS in 64-bit fixed point and
+/* The same scatter without global atomics: every corner contribution (on the coarse levels: what a wave's 64 samples
+ * x P points contribute to one entry, summed in LDS first; on the fine levels: the two x-neighbours of a corner pair as
+ * ONE 16-byte record) is appended to the region of its 64-KB gradient bin, then each bin is accumulated in LDS in 64-bit fixed point and
  * added to the table (see hashgrid.hip).  fp32 contributions throughout; a level that receives a non-finite
  * contribution is filled with NaN (what the float atomics of the reference would have left in the table).
  * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
