@@ -736,9 +736,9 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
     __shared__ float lmax_all[kWaves][MI3D_MAX_LEVELS];
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    // two roles in one launch: the first waves_a waves emit the levels of mask_a (the fine, store-bound group: they are
-    // dispatched first and take their 2 workgroups per CU), the next waves_b waves the levels of mask_b (the coarse,
-    // latency-bound group, which fills the rest of the machine and hides under the first)
+    // two roles in one launch: the first waves_a waves emit the levels of mask_a (the fine group, x-pair records per
+    // point: dispatched first), the next waves_b waves the levels of mask_b (the coarse group, gathered per tile), which
+    // share the machine with them - at C2 the two roles are about equally long
     uint32_t gw = blockIdx.x * kWaves + wave_in_wg;
     const bool role_b = gw >= waves_a;
     if (role_b) gw -= waves_a;
@@ -751,11 +751,11 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
     if (lane < MI3D_MAX_LEVELS) lmax_all[wave_in_wg][lane] = 0.f;
     if (gw >= n_waves) return;
 
-    // The (tile, level) pairs of this wave, in one of two orders.  Tile-major (coarse role): the positions of a tile are
-    // loaded once for all its levels.  Level-major (fine role): the wave appends to the 64 regions of ONE level at a time,
-    // so the lines it has open - 1536 waves x 64 bins x 128 B = 12.6 MB against 100 MB with all eight fine levels open -
-    // stay in the L2s until they are full; partially written lines that get evicted cost the store path 2.4x
-    // (tools/store_bench.hip, profiles/store_bench_r02.txt: 184 G vs 75 G scattered 16-byte records per second).
+    // The (tile, level) pairs of this wave.  Tile-major (the product's order for both roles): the positions of a tile are
+    // loaded once for all its levels.  Level-major for the fine role is a development switch (csrc/mi3d_dev.h
+    // MI3D_T_EMIT_ORDER): the wave then appends to the 64 regions of ONE level at a time, 12.6 MB of open lines chip-wide
+    // instead of 100 MB - which doubles the rate of the bare store pattern (tools/store_bench.hip,
+    // profiles/store_bench_r02.txt: 184 G vs 75 G records/s) but not of this kernel: measured 2 ms slower, twice.
     const uint32_t nl = (uint32_t)__popc(level_mask);
     const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
     const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
             // ALL gradient pairs of this (tile, level) are fetched before its first record is stored.  gfx950 has one
             // counter for vector loads and stores (vmcnt), and the compiler cannot count the conditional stores between a
             // load and its use - so a load consumed inside the point loop costs "s_waitcnt vmcnt(0)": a full drain of the
-            // wave's scattered stores, once per point (that was the emit's bound: ~4 us per point).  Up front it is one
-            // drain per 13 points; the pairs wait in registers as raw bits and are picked by a select chain (p is uniform).
+            // wave's scattered stores, once per point.  Up front it is one drain per 13 points; the pairs wait in
+            // registers as raw bits and are picked by a select chain (p is uniform).
             // point-major rows: the pair of (sample s, point p) sits at plane[p * n_rows + s] - 512 contiguous bytes per wave
             // (unconditional loads from clamped rows - a predicated load makes the compiler wait for it on the spot; what
             // an invalid lane or a point >= P fetched is never looked at)
