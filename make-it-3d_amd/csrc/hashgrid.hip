@@ -163,7 +163,9 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 //   NT     the planes are written once and read by another kernel: stored non-temporally they stop evicting the
 //          level's 4 MB table from the XCD's 4 MB L2 (FETCH_SIZE showed 41 GB of table re-fetches per launch against
 //          49 MB of tables): 34.6 -> 30.4 ms with binary16 planes (loading the positions non-temporally as well: no change).
-// Measured and rejected: non-temporal loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
+// Measured and rejected: keeping a tile's 13 results in registers and storing them after the last point, so that no
+// store sits between the gathers in the shared load/store counter (30.99 -> 31.45 ms, bit-identical); non-temporal
+// loads on the saturated levels (3.8 -> 10.9 ms per level); more than 3 workgroups
 // per CU (+2-6 ms); evaluating the stencil three points at a time with the +-eps x-neighbours adjacent and all 24 loads
 // in flight (35.6 -> 36.0 ms: the coarse levels lose to the lower occupancy what the fine ones gain); keeping the corner values of the sample's own cell in registers for its +-eps neighbours (the
 // coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
