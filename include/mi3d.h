@@ -194,6 +194,20 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                              void *workspace, size_t workspace_bytes, float *grad_params, void *stream);
 
+/* Host-side planning queries: no device work, callable without a GPU (tests/test_plan_cpu.py).
+ * mi3d_grid_encode_plan: how mi3d_grid_encode_points_planes cuts the (level, tile-of-64-samples) list into one run of
+ *   segments per XCD: n_segments[8], segments[8][16][3] = (level, first tile, end tile).
+ * mi3d_grid_scatter_plan: how mi3d_grid_scatter_binned lays out its workspace for n samples and `workspace_bytes`:
+ *   out[0] samples per slice, out[1] workspace bytes one slice uses, out[2] coarse levels (gathered per tile),
+ *   out[3] reduce workgroups, out[4] record-arena bytes, out[5] region counters, then 7 values per level: bins, region
+ *   capacity (records), emitting waves, 1 = 16-byte x-pair records, reduce workgroups per bin, first reduce workgroup,
+ *   first region counter.  out must hold 6 + 7 * n_levels values. */
+int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
+                          float per_level_scale, uint32_t log2_hashmap_size, uint32_t *n_segments, uint32_t *segments);
+int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
+                           float per_level_scale, uint32_t log2_hashmap_size, size_t workspace_bytes,
+                           unsigned long long *out);
+
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 
 /* network_tcnn.py:13-32: y = W3 relu(W2 relu(W1 x + b1) + b2) + b3, torch nn.Linear layout (W_l is [out_l, in_l]

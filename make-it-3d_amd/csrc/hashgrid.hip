@@ -1351,24 +1351,53 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
 }
 
 
-#ifdef MI3D_DEV
-// development build only (tools/bin/libmi3d_dev.so): the record-arena plan of one slice, for tools/ scripts that look
-// at region fill.  out[0] = arena bytes, out[1] = counters, out[2] = merge levels, then per level: bins, cap, waves,
-// first counter, row flag.
-void mi3d_dev_scatter_plan(uint32_t n_slice, uint32_t P, float bound, float step, uint32_t n_levels,
-                           uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+// Host-side planning queries (no device work; they run without a GPU): what the two calls above will do.
+int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
+                          float per_level_scale, uint32_t log2_hashmap_size, uint32_t *n_segments, uint32_t *segments) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || n_segments == nullptr || segments == nullptr)
+        return (int)hipErrorInvalidValue;
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
+    const EncodePlan plan = make_encode_plan(T, (n + kTile - 1) / kTile, step01, -1);
+    for (uint32_t x = 0; x < kXcds; ++x) {
+        n_segments[x] = plan.n_seg[x];
+        for (uint32_t i = 0; i < (uint32_t)kMaxSegs; ++i) {
+            const EncodeSeg sg = i < plan.n_seg[x] ? plan.seg[x][i] : EncodeSeg{0u, 0u, 0u};
+            segments[(x * kMaxSegs + i) * 3 + 0] = sg.level;
+            segments[(x * kMaxSegs + i) * 3 + 1] = sg.tile0;
+            segments[(x * kMaxSegs + i) * 3 + 2] = sg.tile1;
+        }
+    }
+    return 0;
+}
+
+int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
+                           float per_level_scale, uint32_t log2_hashmap_size, size_t workspace_bytes,
                            unsigned long long *out) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || n == 0 || out == nullptr)
+        return (int)hipErrorInvalidValue;
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     const uint32_t merge_levels = default_merge_levels(T, step01 * (3.0f / 1.05f));
-    const BinPlan p = plan_for(T, n_slice, P, step01, merge_levels);
-    out[0] = p.total_bytes; out[1] = p.total_counts; out[2] = merge_levels;
-    for (uint32_t l = 0; l < n_levels; ++l) {
-        out[3 + 5 * l] = level_bins(T.level[l]); out[4 + 5 * l] = p.level_cap[l]; out[5 + 5 * l] = p.level_waves[l];
-        out[6 + 5 * l] = p.level_cnt0[l]; out[7 + 5 * l] = (p.row_mask >> l) & 1u;
+    uint64_t n_slice = n;  // the same halving mi3d_grid_scatter_binned does
+    BinPlan p = plan_for(T, n_slice, P, step01, merge_levels);
+    while (n_slice > kWave && bin_workspace_bytes(p) > workspace_bytes) {
+        n_slice = (n_slice + 1) / 2;
+        p = plan_for(T, n_slice, P, step01, merge_levels);
     }
+    const uint64_t evals = n_slice * P;
+    plan_reduce_splits(p, T, evals >= 30000000ull ? 4u : (evals >= 8000000ull ? 2u : 1u), merge_levels);
+    out[0] = n_slice; out[1] = bin_workspace_bytes(p); out[2] = merge_levels; out[3] = p.n_reduce_wgs;
+    out[4] = p.total_bytes; out[5] = p.total_counts;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        unsigned long long *o = out + 6 + 7 * l;
+        o[0] = level_bins(T.level[l]); o[1] = p.level_cap[l]; o[2] = p.level_waves[l]; o[3] = (p.row_mask >> l) & 1u;
+        o[4] = p.level_split[l]; o[5] = p.level_wg0[l]; o[6] = p.level_cnt0[l];
+    }
+    return 0;
 }
-#endif
+
 
 }  // extern "C"

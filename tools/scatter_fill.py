@@ -48,13 +48,14 @@ def main():
     L.call("mi3d_grid_scatter_binned", L.ptr(xs), L.ptr(xs2), n_slice, offs_p, int(P0), P, 1.0, L.ptr(g), 1, 16, 16, pls,
            19, step, L.ptr(ws), C.c_size_t(need), L.ptr(grad), L.stream())
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 96)()
-    lib.mi3d_dev_scatter_plan(n_slice, P, C.c_float(1.0), C.c_float(step), 16, 16, C.c_float(pls), 19, out)
-    total_bytes, total_counts, merge = out[0], out[1], out[2]
+    out = (C.c_ulonglong * (6 + 7 * 16))()
+    L.call("mi3d_grid_scatter_plan", n_slice, P, 1.0, step, 16, 16, pls, 19, C.c_size_t(need), out)
+    assert out[0] == n_slice
+    total_bytes, total_counts, merge = out[4], out[5], out[2]
     counts = ws[total_bytes: total_bytes + 4 * total_counts].view(torch.int32)
     res = {"samples_in_slice": n_slice, "merge_levels": int(merge), "levels": []}
     for l in range(16):
-        bins, cap, waves, c0, row = (int(out[3 + 5 * l + k]) for k in range(5))
+        bins, cap, waves, row, _split, _wg0, c0 = (int(out[6 + 7 * l + k]) for k in range(7))
         c = counts[c0: c0 + waves * bins].view(waves, bins).float()
         per_bin = c.sum(0)
         res["levels"].append({"level": l, "bins": bins, "cap": cap, "waves": waves, "row_records": bool(row),
