@@ -82,7 +82,7 @@ def pmc_traffic(kernel, workload, evals):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's
     evaluation count; None if not collected."""
-    for name in ("pmc_r02.json", "pmc_r01.json"):
+    for name in ("pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
             return rec["hbm_bytes_per_eval"] * evals
@@ -91,10 +91,81 @@ def pmc_traffic(kernel, workload, evals):
     return None
 
 
-def cpu_baseline_reference(wl, budget_s=20.0):
-    """The reference's own PyTorch renderer on the host cores: NeRFRenderer.run (renderer.py:332-479, max_steps
-    uniform samples per ray, no importance pass) + NeRFNetwork.forward / normal (13 field evaluations per sample with
-    the smoothness term) on a torch hash grid, forward + backward of a render loss, on a ray sample of the same view."""
+def _c1_network(ref_import, device="cpu"):
+    """BASELINE config 1's field on the REFERENCE's classes: L=4 hash grid (16/81/407/2048) + Linear(8,32)-ReLU-
+    Linear(32,4), table U(-1e-4, 1e-4), default nn.Linear init, blob 5 / 0.1, seed 0."""
+    import torch
+    from nerf.network_tcnn import MLP
+    from oracle import oracle as O
+    from oracle.field_torch import HashGridTorch
+    torch.manual_seed(0)
+    c1 = O.GridConfig(n_levels=4, per_level_scale=128 ** (1 / 3))
+    net = ref_import.reference_network(ref_import.default_opt(cuda_ray=False, lambda_smooth=0.0), "oracle",
+                                       num_layers=2, hidden_dim=32)
+    net.encoder = HashGridTorch(c1)
+    net.sigma_net = MLP(c1.n_output_dims, 4, 32, 2, bias=True)
+    return net.to(device)
+
+
+def cpu_baseline_c1():
+    """BASELINE.md section 2, to the letter: the reference's own NeRFRenderer.run (nerf/renderer.py:332-479) on config 1
+    WHOLE - 64x64 rays of the orbit pose, 64 samples per ray, no importance pass, L=4 + 2x32 field, fp32, bg ones -
+    forward only and forward + backward, 3 warm-up + 10 timed calls each, median."""
+    import statistics
+    import torch
+    from mi3d import rays as R
+    from oracle import ref_import
+    ref_import.install()
+    cores = min(os.cpu_count() or 1, 32)   # beyond a few dozen threads these small gather / index_add ops slow down
+    torch.set_num_threads(cores)
+    net = _c1_network(ref_import)
+    net.train()
+    ro, rd, _ = R.view_rays(64, 64)
+    N, steps = ro.shape[1], 64
+    bg = torch.ones(N, 3)
+
+    def forward():
+        return net.run(ro, rd, num_steps=steps, upsample_steps=0, bg_color=bg, perturb=True, ambient_ratio=1.0,
+                       shading="albedo")
+
+    def fwd_only():
+        with torch.no_grad():
+            forward()
+
+    def fwd_bwd():
+        net.zero_grad()
+        out = forward()
+        ((out["image"] ** 2).mean() + out["loss_orient"]).backward()
+
+    def timed(fn, warm=3, n=10, budget=45.0):
+        t_start = time.perf_counter()
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget and len(ts) >= 3:
+                break
+        return statistics.median(ts), len(ts)
+    tf, nf = timed(fwd_only)
+    tb, nb = timed(fwd_bwd)
+    m = N * steps
+    return {"value": 1.0 / tb, "unit": "C1 view-steps/s (64x64 render forward + backward, no diffusion)", "cores": cores,
+            "kind": "reference",
+            "sample": f"BASELINE config 1 whole: {N} rays x {steps} samples ({m} samples, 7 field evaluations each) through "
+                      f"the reference's NeRFRenderer.run + NeRFNetwork (L=4 torch hash grid + 2x32 MLP), fp32; median of "
+                      f"{nf} forward / {nb} forward+backward calls after 3 warm-ups",
+            "forward_ms": 1e3 * tf, "forward_backward_ms": 1e3 * tb,
+            "forward_rays_per_s": N / tf, "forward_samples_per_s": m / tf,
+            "forward_backward_rays_per_s": N / tb, "forward_backward_samples_per_s": m / tb}
+
+
+def cpu_baseline_reference(wl, budget_s=60.0, min_rays=256):
+    """Labelled extra: the headline workload's own shape (max_steps uniform samples per ray, 13 field evaluations per
+    sample with the smoothness term, L=16 + 3x64) through the reference's NeRFRenderer.run + NeRFNetwork on a torch
+    hash grid, forward + backward, on >= 256 rays of the same view, extrapolated to the full view."""
     import torch
     from mi3d import rays as R
     from oracle import ref_import
@@ -119,17 +190,15 @@ def cpu_baseline_reference(wl, budget_s=20.0):
         loss = (out["image"] ** 2).mean() + out["loss_orient"] + out["loss_smooth"]
         loss.backward()
 
-    # the torch hash grid pays a large fixed cost per pass (a dense 48.8 MB gradient per encoder call), so grow the
-    # sample until one render fills about half the budget - a tiny sample would charge that fixed cost to a few rays
-    n, dt, spent = 8, 0.0, 0.0
-    for _ in range(4):
+    n = min(N, min_rays)
+    t0 = time.perf_counter()
+    render(n)
+    dt = time.perf_counter() - t0
+    if dt < 0.25 * budget_s and n < N:   # room for a larger sample: the fixed per-pass cost shrinks relative to it
+        n = int(min(N, n * 0.6 * budget_s / max(dt, 1e-3)))
         t0 = time.perf_counter()
         render(n)
         dt = time.perf_counter() - t0
-        spent += dt
-        if dt >= 0.5 * budget_s or n >= N or spent >= 2 * budget_s:
-            break
-        n = int(min(N, max(n + 1, min(16 * n, n * 0.8 * budget_s / max(dt, 1e-3)))))
     return {"value": (n / N) / dt, "unit": "view-steps/s (render + backward only, no diffusion)", "cores": cores,
             "kind": "reference",
             "sample": f"{n} of {N} rays x {steps} samples x 13 field evaluations of the same view through the "
@@ -179,22 +248,32 @@ def log(msg):
     sys.stderr.flush()
 
 
-def cpu_baseline(workload, hard_limit_s=150):
-    """Runs in a child process with a hard wall-clock limit (the leg must never hold the bench line hostage): the
-    reference's PyTorch renderer when the staged sources exist, else - or on timeout / failure - the C port."""
-    for kind in ("reference", "port"):
-        try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload",
-                                  workload], capture_output=True, text=True, timeout=hard_limit_s)
-            for ln in reversed(out.stdout.strip().splitlines()):
-                if ln.startswith("{"):
-                    return json.loads(ln)
-            log(f"cpu baseline ({kind}) printed no result: {out.stderr[-300:]}")
-        except subprocess.TimeoutExpired:
-            log(f"cpu baseline ({kind}) exceeded {hard_limit_s} s")
-        except Exception as e:
-            log(f"cpu baseline ({kind}) failed: {e!r}")
-    return {"value": None, "error": "both CPU baseline legs failed"}
+def _cpu_leg(kind, workload, hard_limit_s):
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload",
+                              workload], capture_output=True, text=True, timeout=hard_limit_s)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        log(f"cpu baseline ({kind}) printed no result: {out.stderr[-300:]}")
+    except subprocess.TimeoutExpired:
+        log(f"cpu baseline ({kind}) exceeded {hard_limit_s} s")
+    except Exception as e:
+        log(f"cpu baseline ({kind}) failed: {e!r}")
+    return None
+
+
+def cpu_baseline(workload):
+    """Child processes with hard wall-clock limits (the legs must never hold the bench line hostage).  Primary:
+    BASELINE config 1 whole through the reference's own renderer; extra: the headline workload's
+    shape on >= 256 rays, extrapolated; the C oracle port only when the staged reference sources are absent."""
+    res = _cpu_leg("c1", workload, 150)
+    extra = _cpu_leg("reference", workload, 150) if WORKLOADS[workload].get("mode") is None else None
+    if res is None:
+        res = extra or _cpu_leg("port", workload, 150) or {"value": None, "error": "every CPU baseline leg failed"}
+    elif extra is not None:
+        res["headline_shape_extrapolated"] = extra
+    return res
 
 
 def spawn_ranks(n):
@@ -217,16 +296,18 @@ def main():
     ap.add_argument("--no-reference-shaped", action="store_true")
     ap.add_argument("--init-scale", type=float, default=65536.0,
                     help="GradScaler initial loss scale (the reference's: torch's default, nerf/utils.py:309)")
-    ap.add_argument("--cpu-baseline-only", default=None, choices=["reference", "port"], help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-only", default=None, choices=["c1", "reference", "port"], help=argparse.SUPPRESS)
+    ap.add_argument("--refresh-every", type=int, default=16,
+                    help="update_extra_state interval inside the timed loop (nerf/utils.py:970-972; 0 = never)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:   # child process of cpu_baseline(): host cores only, no GPU
         wl = WORKLOADS[args.workload]
-        if args.cpu_baseline_only == "reference":
+        if args.cpu_baseline_only in ("c1", "reference"):
             from oracle import ref_import
             if not ref_import.available():
                 raise SystemExit("reference sources not staged")
-            print(json.dumps(cpu_baseline_reference(wl)))
+            print(json.dumps(cpu_baseline_c1() if args.cpu_baseline_only == "c1" else cpu_baseline_reference(wl)))
         else:
             print(json.dumps(cpu_baseline_port(wl)))
         return
@@ -285,14 +366,35 @@ def main():
         if render_only:
             return render_step
 
+        clock = {"i": 0, "refreshes": 0}
+
+        def refresh():
+            # nerf/utils.py:970-972: every update_extra_interval (16) steps, before the step, under autocast.  Rank 0
+            # evaluates the 128^3 jittered cell centres (2.1 M field evaluations per cascade), EMA-maxes the grid,
+            # thresholds and repacks the bitfield; the other ranks receive grid + bitfield (mi3d/dp.py:sync_occupancy,
+            # SURVEY 8(e)).  A random-weight field has near-constant density, so what the refresh computes is all-on or
+            # blob-only depending on the seed: the workload's ANALYTIC occupancy is put back afterwards
+            # (a 262 144-byte fill - not something the reference does, and the only part of this that is not).
+            with grid_ops.phase("grid_refresh"):
+                if rank == 0:
+                    with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+                        the_model.update_extra_state()
+                dp.sync_occupancy(the_model)
+                sds_step.set_bitfield(the_model, wl["bitfield"])
+            clock["refreshes"] += 1
+
         def step():
             # a batch of `views` views is `views` consecutive single-view passes (the renderer "assumes B == 1",
             # renderer.py:482), each a full training step as the reference's loader (batch_size 1) would issue them
             for ro, rd, ds in view_rays:
+                if args.refresh_every > 0 and clock["i"] % args.refresh_every == 0:
+                    refresh()
+                clock["i"] += 1
                 if sync is not None:
                     bucket.zero()
                 sds_step.sds_train_step(the_model, guidance, text_z, the_optimizer, the_scaler, ro, rd, ds, wl["H"],
                                         wl["W"], opt, sds_backward=schedule, t=t_fixed, grad_sync=sync)
+        step.clock = clock
         return step
 
     # phase timers (HIP events on the launch stream) around the two PyTorch-side phases
@@ -309,9 +411,16 @@ def main():
 
     def run(records, schedule, steps, warmup):
         step = make_step(model, optimizer, scaler, schedule, bucket.all_reduce_mean)
+        if not render_only:
+            step.clock["i"] = 1   # warm-up steps do not refresh the grid ...
         for _ in range(warmup):
             step()
+        if not render_only:
+            step.clock["i"] = 0   # ... the first timed step does (global_step 0 of nerf/utils.py:970), then every 16th
+            step.clock["refreshes"] = 0
         grid_ops.PROFILE = {"scatter": [], "encode": []}
+        torch.cuda.reset_peak_memory_stats(dev)
+        scale0 = scaler.get_scale() if not render_only else None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -327,11 +436,11 @@ def main():
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        applied = len(prof.get("optimizer", []))
-        if not render_only and applied != steps * views:
-            raise SystemExit(f"bench invalid: only {applied} of {steps * views} timed passes applied their optimizer "
-                             f"update (GradScaler overflow, scale now {scaler.get_scale()})")
-        return elapsed, prof
+        info = {"applied": len(prof.get("optimizer", [])), "scale_before": scale0,
+                "scale_after": scaler.get_scale() if not render_only else None,
+                "refreshes": 0 if render_only else step.clock["refreshes"],
+                "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        return elapsed, prof, info
 
     log(f"{args.workload}: timing {args.steps} steps of the headline variant {HEADLINE} on {world} GPU(s)")
     # settle the loss scale (untimed; before the W warm-up steps of the contract)
@@ -343,37 +452,63 @@ def main():
         good = good + 1 if scaler.get_scale() >= before else 0
         tries += 1
     if not render_only and opt.fp16:
-        # two halvings of margin below the scale at which 4 consecutive steps applied: the noise of later steps (other
-        # views on other ranks, other jitter) must not overflow a timed step - GradScaler itself would sit between the
-        # two, skipping a step now and then
-        settled = scaler.get_scale()
-        scaler.update(new_scale=settled / 4.0)
-        log(f"loss scale: 4 consecutive steps applied at {settled} after {tries} untimed steps; timing at {settled / 4.0}")
-    elapsed, prof = run(*HEADLINE, args.steps, args.warmup)
-    log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step")
+        # timed AT the scale the scaler settled at (round 2 timed two halvings below it: fewer binary16 gradients survive
+        # there, so the scatter did less work than a training run's).  A timed step may still overflow - GradScaler
+        # then skips that optimizer update and halves, exactly as in training; the line reports how many updates were
+        # applied and the scale before / after instead of aborting.
+        log(f"loss scale: 4 consecutive steps applied at {scaler.get_scale()} after {tries} untimed steps; timing there")
+    elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
+    log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of {args.steps * views} updates applied, "
+        f"loss scale {info['scale_before']} -> {info['scale_after']}, peak memory {info['peak_mem_GiB']:.1f} GiB")
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
     if args.variant_steps > 0 and not render_only:
-        e, _ = run("fp32", "single", args.variant_steps, 1)
+        e, _, _ = run("fp32", "single", args.variant_steps, 1)
         variants["records=fp32,sds_backward=single"] = 1e3 * e / args.variant_steps
 
+    # ---- untimed: which gradient pairs one step's scatters actually carry, and the scatter on dense gradients
+    census, dense = None, None
+    if not render_only:
+        grid_ops.CENSUS = []
+        make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)()
+        torch.cuda.synchronize()
+        raw, grid_ops.CENSUS = grid_ops.CENSUS, None
+        census = {}
+        for c in raw:
+            nz = [int(v) for v in c["nonzero_pairs_per_level"].tolist()]
+            census[c["P_active"]] = {"rows": c["rows"], "nonzero_pair_fraction_per_level": [v / c["rows"] for v in nz],
+                                     "nonzero_pair_fraction": sum(nz) / (len(nz) * c["rows"])}
+        if rank == 0 and world == 1:
+            dense = scatter_on_dense_gradients(model, view_rays[0], opt, dev)
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
     line = None
     if rank == 0:
         ms = {k: [a.elapsed_time(b) for a, b in v] for k, v in prof.items() if not k.endswith("_evals")}
         evals = {k[:-6]: v for k, v in prof.items() if k.endswith("_evals")}
 
-        def roof(kernel, key, per_eval, bound, peak, unit, note, pmc_key=None):
+        def roof(kernel, key, per_eval, bound, peak, unit, note, pmc_key=None, work_of=None):
+            """achieved = algorithmic work of the timed launches / their summed HIP-event duration.  work_of(evals of
+            one launch) overrides evals x per_eval (the scatter counts only the pairs it does not skip)."""
             t = sum(ms.get(key, [])) * 1e-3
-            work = sum(evals.get(key, [])) * per_eval
+            ev = evals.get(key, [])
+            work = sum(work_of(e) for e in ev) if work_of else sum(ev) * per_eval
             a = work / t / (1e9 if bound == "hbm" else 1e12) if t > 0 else 0.0
             n_launch = max(1, len(ms.get(key, [])))
             traffic = None
             if pmc_key is not None:
-                traffic = pmc_traffic(pmc_key, args.workload, sum(evals.get(key, [])) / n_launch)
+                traffic = pmc_traffic(pmc_key, args.workload, sum(ev) / n_launch)
             return {"kernel": kernel, "bound": bound, "achieved": a, "peak": peak, "unit": unit, "frac": a / peak,
                     "traffic": traffic, "launches": len(ms.get(key, [])), "avg_launch_ms": 1e3 * t / n_launch,
                     "ms_per_step": 1e3 * t / args.steps,
                     "algorithmic_work_per_launch": work / n_launch, "note": note}
+
+        n_last = m + (128 - m % 128)   # rows of the last view (march pads past the next multiple of 128)
+
+        def scatter_work(ev):
+            """2048 B per evaluation = 128 B per (evaluation, level) gradient pair - counted only for the pairs that are
+            not exactly zero (the census of one untimed step at the same state; the emit skips the others)."""
+            P_act = 1 if ev < 2 * n_last else 13
+            c = (census or {}).get(P_act)
+            return ev * SCATTER_BYTES_PER_EVAL * (c["nonzero_pair_fraction"] if c else 1.0)
 
         roofs = [
             roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, "
@@ -381,16 +516,20 @@ def main():
                  "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
                  "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
                  "k_grid_encode_planes"),
-            roof("grid gradient scatter = k_bin_emit + k_bin_reduce per slice (records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
-                 "GB/s", "algorithmic bytes = 2048 B per evaluation read-modify-write of the table; the binned path "
-                 "moves 4 x-pair records x 16 B per (evaluation, fine level) out and back instead; one call per NeRF backward: the "
-                 "SDS pass reaches stencil point 0 only (1/13 of the evaluations), the regulariser pass all 13",
-                 "scatter_binned"),
+            roof("grid gradient scatter: one mi3d_grid_scatter_binned call = (k_bin_emit + k_bin_reduce) x slices "
+                 "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
+                 "GB/s", "a 'launch' here is one scatter call (kernel-trace: sum the k_bin_emit and k_bin_reduce rows of a "
+                 "step); algorithmic bytes = 2048 B per evaluation read-modify-write of the table, counted ONLY for the "
+                 "(evaluation, level) gradient pairs that are not exactly zero (grad_nonzero_pair_fraction: binary16 "
+                 "gradients underflow, and adding a zero is what the reference's atomics would do); the dense-gradient "
+                 "figure is scatter_dense_gradients.  One call per NeRF backward: the SDS pass reaches stencil point 0 "
+                 "only (1/13 of the evaluations), the regulariser pass all 13",
+                 "scatter_binned", work_of=scatter_work),
             roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
                  "streams 64 B of binary16 planes in + 16 B out per evaluation (fp32 planes without autocast: 128 B)", "k_mlp_forward"),
-            roof("k_mlp_backward<F16> (recompute + dgrad + wgrad, both orientations, next tile prefetched)", "mlp_bwd",
+            roof("k_mlp_backward<F16> (recompute + dgrad + wgrad in one kernel)", "mlp_bwd",
                  25600.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
-                 "80 B read + 64 B written per evaluation with binary16 planes; 67 MFMAs per 32 rows", "k_mlp_backward"),
+                 "80 B read + 64 B written per evaluation with binary16 planes", "k_mlp_backward"),
         ]
         roofs.sort(key=lambda r: -r["ms_per_step"])
         line = {
@@ -418,14 +557,25 @@ def main():
                                     f"branch of nerf/sd.py:153), occupancy {wl['bitfield']}, {m} samples/view x 13 "
                                     f"field evaluations, {views} view(s) per step",
                         "views_per_step": world * views, "sds_backward": HEADLINE[1], "gradient_records": HEADLINE[0],
-                        "optimizer_steps_applied": args.steps * views, "grad_scaler_scale": scaler.get_scale(),
+                        "optimizer_steps_applied": info["applied"], "optimizer_steps_attempted": args.steps * views,
+                        "grad_scaler_scale": info["scale_before"], "grad_scaler_scale_after": info["scale_after"],
+                        "grid_refreshes_in_timed_region": info["refreshes"],
                         "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad "
                                        f"all-reduce)"}),
             "variants_ms_per_step": variants,
             "roofline": roofs[0],
             "rooflines_other": roofs[1:],
-            "kernels_ms_per_step": {k: sum(v) / args.steps for k, v in ms.items()},
+            "kernels_ms_per_step": {k: sum(v) / args.steps for k, v in ms.items() if not k.startswith("phase:")},
+            # exclusive phases of the step (HIP events on the launch stream): their sum is the step
+            "phases_ms_per_step": {k[6:]: sum(v) / args.steps for k, v in ms.items() if k.startswith("phase:")},
+            "peak_mem_GiB": info["peak_mem_GiB"],
         }
+        line["phases_ms_per_step"]["unattributed"] = line["ms_per_step"] - sum(line["phases_ms_per_step"].values())
+        if census is not None:
+            line["grad_nonzero_pair_fraction"] = {
+                ("sds_pass_point0" if k == 1 else f"regulariser_pass_{k}_points"): v for k, v in sorted(census.items())}
+        if dense is not None:
+            line["scatter_dense_gradients"] = dense
 
     # ---- baselines (rank 0 of a single-GPU run only; never part of the timed region above)
     if rank == 0 and world == 1:
@@ -446,6 +596,42 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def scatter_on_dense_gradients(model, rays, opt, dev, reps=2):
+    """The 13-point scatter of this view on DENSE random binary16 gradient planes (no pair is zero): the figure to hold
+    against the real step's, whose work depends on how many binary16 gradients underflowed."""
+    import math
+    import raymarching
+    import torch
+    from mi3d import field_ops, grid_ops
+    ro, rd, _ = rays
+    ro, rd = ro.view(-1, 3).contiguous(), rd.view(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, model.aabb_train)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    xs, _, _, _ = raymarching.march_rays_train(ro, rd, model.bound, model.density_bitfield, model.cascade,
+                                               model.grid_size, nears, fars, cnt, -1, True, 128, True, opt.dt_gamma,
+                                               opt.max_steps)
+    xs = xs.contiguous()
+    x2 = (xs + torch.randn_like(xs) * 1e-2).contiguous()
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    n, P, cfg = xs.shape[0], offs.shape[0], model.encoder.cfg
+    g = torch.randn(cfg["n_levels"], P * n, 2, device=dev).to(torch.float16)
+    step = 2 * math.sqrt(3) / opt.max_steps
+
+    def call():
+        return field_ops.scatter_binned(xs, x2, offs, P0, float(model.bound), g, cfg, step, model.encoder.params.numel())
+    call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    a = n * P * SCATTER_BYTES_PER_EVAL / t / 1e9
+    return {"ms": 1e3 * t, "evaluations": n * P, "achieved": a, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+            "frac": a / HBM_PEAK_GBPS, "what": "13-point mi3d_grid_scatter_binned on dense random binary16 gradients"}
 
 
 def bench_refine(args, wl, dev, rank, world):

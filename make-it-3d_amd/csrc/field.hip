@@ -93,21 +93,21 @@ struct F16 {
         }
         return k;
     }
-    // gradient tile masked by the ReLU of `act` (a K-block from relu()): packed convert, then per binary16 lane
-    // AND with 0xFFFF where act != 0 - min(act, 1) * 0xFFFF in packed u16 arithmetic.  (Written as inline asm: the
+    // gradient tile masked by the ReLU of `act` (a K-block from relu()): packed convert, then per binary16 lane the
+    // bit pattern times min(act bits, 1) in packed u16 arithmetic - the pattern itself where act != 0, else +0.  (Written as inline asm: the
     // optimiser canonicalises every C spelling of it into 16 compares + 16 selects + 16 scalar converts per K-block,
     // which made the masks a third of the kernel's instructions.)
     __device__ static __forceinline__ KB masked(const f32x16 &d, const KB &act) {
         KB k;
-        const unsigned ones = 0x00010001u, full = 0xFFFFFFFFu;
+        const unsigned ones = 0x00010001u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const f32x2 pr = {d[2 * j], d[2 * j + 1]};
             const half2v hv = __builtin_convertvector(pr, half2v);
             const half2v av = {act.v[j >> 2][2 * (j & 3)], act.v[j >> 2][2 * (j & 3) + 1]};
             unsigned m = __builtin_bit_cast(unsigned, av), dv = __builtin_bit_cast(unsigned, hv);
-            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %3\n\tv_and_b32 %0, %0, %4"
-                : "=&v"(m) : "v"(m), "s"(ones), "s"(full), "v"(dv));
+            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %3"
+                : "=&v"(m) : "v"(m), "s"(ones), "v"(dv));
             const half2v r = __builtin_bit_cast(half2v, m);
             k.v[j >> 2][2 * (j & 3)] = r[0];
             k.v[j >> 2][2 * (j & 3) + 1] = r[1];
@@ -354,7 +354,7 @@ __device__ __forceinline__ f32x16 bias_rows(const float *bias, int h) {
 }
 // ---------------------------------------------------------------- forward
 template <class P>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void k_mlp_forward(const float *__restrict__ x, uint32_t x_planes, int x_half,
+__global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_forward(const float *__restrict__ x, uint32_t x_planes, int x_half,
                                                                      uint32_t n, Weights w, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *bias = reinterpret_cast<float *>(lds + (size_t)B_FWD_COUNT * block_bytes<P>());
@@ -790,6 +790,451 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
     }
 }
 
+// ================================================================ generic kernels (round 3)
+// The same dataflow for every shape the reference's MLP class builds around this field (network_tcnn.py:13-32,67 takes
+// num_layers and hidden_dim; BASELINE config 1 is Linear(8,32)-ReLU-Linear(32,4)): dim_in even and <= 32 (padded to one
+// K-block with zero weights), dim_hidden 32 or 64, 2 or 3 layers, dim_out 4 - and a different register plan.
+//
+// What round 2's profile showed (rocprofv3 + the ISA of k_mlp_backward): 12.0 ms for 141 M rows whatever the staging -
+// one tile at a time, two, prefetch or not - because the kernel was bound by INSTRUCTION ISSUE of its single wave per
+// SIMD: 1175 instructions per 32-row tile, 40 % of them v_accvgpr_read / _mov.  hipcc puts every MFMA result into the
+// accumulator file as soon as a kernel may use more than 256 registers (one wave per SIMD), and VALU cannot read AGPRs,
+// so each of the 16 values of every product paid a move before its convert.  Here the kernels are held to TWO waves
+// per SIMD (<= 256 registers, __launch_bounds__(256, 2)): the compiler then selects the VGPR form of every MFMA and
+// there is no accumulator file at all, the second wave fills the issue slots the first one leaves under its matrix
+// products, and the operands of the weight gradients (which need "lane = feature, registers = samples") come from
+// TRANSPOSING the orientation-1 tiles on the matrix core (a product with an identity block: 2 MFMAs and 8 converts per
+// K-block) instead of recomputing the layers in the second orientation (4 MFMAs, 16-32 converts / masks and a bias
+// splat per K-block): 61 MFMAs and ~520 instructions per tile.
+template <int NTH, int LAYERS> struct Blk {
+    static constexpr int W1 = 0;                                      // [tn]      as B_W1
+    static constexpr int W2 = W1 + NTH;                               // [tn][tk]  as B_W2 (three layers only)
+    static constexpr int W3 = W2 + (LAYERS == 3 ? NTH * NTH : 0);     // [tk]      the LAST layer (4 outputs)
+    static constexpr int FWD_COUNT = W3 + NTH;
+    static constexpr int W3T = FWD_COUNT;                             // [tn]
+    static constexpr int W2T = W3T + NTH;                             // [tn][tk]
+    static constexpr int W1T = W2T + (LAYERS == 3 ? NTH * NTH : 0);   // [tk]
+    static constexpr int IDX = W1T + NTH;                             // identity, K kind X (transposes X and dO)
+    static constexpr int IDD = IDX + 1;                               // identity, K kind D (transposes layer outputs)
+    static constexpr int ALL_COUNT = IDD + 1;
+    static constexpr int BIAS_TILES = 2 * NTH + 1;                    // b1[t], b2[t], b_last: [h][16] floats each
+};
+
+// Operand blocks (layouts as build_blocks above) for hidden width 32 NTH and input width din <= 32, plus the biases as
+// ready-made accumulator tiles: tile i, lane-half h, register q = bias of row rowmap(q, h) - one broadcast 64-byte read
+// per lane initialises an accumulator.
+template <class P, int NTH, int LAYERS>
+__device__ void build_blocks_g(char *lds, float *biasT, const Weights &w, int din, int n_blocks) {
+    using T = typename P::elem;
+    using B = Blk<NTH, LAYERS>;
+    constexpr int H = 32 * NTH;
+    for (int e = threadIdx.x; e < n_blocks * kWave * 16; e += blockDim.x) {
+        const int blk = e / (kWave * 16), r = e % (kWave * 16), lane = r / 16, q = r % 16;
+        const int nl = lane & 31, h = lane >> 5;
+        const int kd = rowmap(q, h), kx = 16 * h + q;
+        float v = 0.f;
+        if (blk < B::W2) {
+            const int tn = blk - B::W1;
+            v = kx < din ? w.W1[(32 * tn + nl) * din + kx] : 0.f;
+        } else if (blk < B::W3) {
+            const int tn = (blk - B::W2) / NTH, tk = (blk - B::W2) % NTH;
+            v = w.W2[(32 * tn + nl) * H + 32 * tk + kd];
+        } else if (blk < B::W3T) {
+            const int tk = blk - B::W3;
+            v = nl < DOUT ? w.W3[nl * H + 32 * tk + kd] : 0.f;
+        } else if (blk < B::W2T) {
+            const int tn = blk - B::W3T;
+            v = kx < DOUT ? w.W3[kx * H + 32 * tn + nl] : 0.f;
+        } else if (blk < B::W1T) {
+            const int tn = (blk - B::W2T) / NTH, tk = (blk - B::W2T) % NTH;
+            v = w.W2[(32 * tk + kd) * H + 32 * tn + nl];
+        } else if (blk < B::IDX) {
+            const int tk = blk - B::W1T;
+            v = nl < din ? w.W1[(32 * tk + kd) * din + nl] : 0.f;
+        } else if (blk == B::IDX) {
+            v = nl == kx ? 1.f : 0.f;
+        } else {
+            v = nl == kd ? 1.f : 0.f;
+        }
+        constexpr int per_unit = 16 / (int)sizeof(T);
+        T *dst = reinterpret_cast<T *>(lds + (size_t)blk * block_bytes<P>() + ((q / per_unit) * kWave + lane) * 16);
+        dst[q % per_unit] = (T)v;
+    }
+    for (int e = threadIdx.x; e < B::BIAS_TILES * 32; e += blockDim.x) {
+        const int tile = e / 32, h = (e % 32) / 16, q = e % 16, row = rowmap(q, h);
+        float v = 0.f;
+        if (tile < NTH) v = w.b1[32 * tile + row];
+        else if (tile < 2 * NTH) v = LAYERS == 3 ? w.b2[32 * (tile - NTH) + row] : 0.f;
+        else v = row < DOUT ? w.b3[row] : 0.f;
+        biasT[e] = P::round(v);
+    }
+}
+__device__ __forceinline__ f32x16 bias_tile(const float *biasT, int tile, int h) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(biasT + (tile * 2 + h) * 16);
+    f32x16 a;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 t = src[c];
+        a[4 * c] = t[0]; a[4 * c + 1] = t[1]; a[4 * c + 2] = t[2]; a[4 * c + 3] = t[3];
+    }
+    return a;
+}
+
+// Rows of a tile for input width din <= 32.  Planes / features past din are read from the last valid one instead of
+// being predicated off (their weights are zero, so whatever finite value they carry contributes nothing).
+__device__ __forceinline__ void load_rows_half_g(const float *__restrict__ x, size_t row, size_t n, int h,
+                                                 size_t plane_rows, uint32_t last_plane, uint32_t (&u)[8]) {
+    row = row < n ? row : n - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t pl = (uint32_t)(8 * h + j) < last_plane ? (uint32_t)(8 * h + j) : last_plane;
+        u[j] = reinterpret_cast<const uint32_t *>(x)[(size_t)pl * plane_rows + row];
+    }
+}
+__device__ __forceinline__ void load_rows_raw_g(const float *__restrict__ x, size_t row, size_t n, int h,
+                                                size_t plane_rows, uint32_t din, float (&raw)[16]) {
+    row = row < n ? row : n - 1;
+    const uint32_t last_plane = din / 2 - 1;
+    if (plane_rows == 0 && din == DIN) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + row * DIN + 16 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 t = src[c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[4 * c + i] = t[i];
+        }
+    } else if (plane_rows == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t f = (uint32_t)(16 * h + q) < din ? (uint32_t)(16 * h + q) : din - 1;
+            raw[q] = x[row * din + f];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t pl = (uint32_t)(8 * h + j) < last_plane ? (uint32_t)(8 * h + j) : last_plane;
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(x + ((size_t)pl * plane_rows + row) * 2);
+            raw[2 * j] = t[0];
+            raw[2 * j + 1] = t[1];
+        }
+    }
+}
+
+template <class P, int NTH, int LAYERS, bool HP>
+__global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_fwd_g(const float *__restrict__ x, uint32_t x_planes,
+                                                                        uint32_t n, uint32_t din, Weights w,
+                                                                        float *__restrict__ out) {
+    using B = Blk<NTH, LAYERS>;
+    using KB = typename P::KB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *biasT = reinterpret_cast<float *>(lds + (size_t)B::FWD_COUNT * block_bytes<P>());
+    build_blocks_g<P, NTH, LAYERS>(lds, biasT, w, (int)din, B::FWD_COUNT);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), p = lane & 31, h = lane >> 5;
+    const uint32_t wave = blockIdx.x * kWavesPerWG + threadIdx.x / kWave, n_waves = gridDim.x * kWavesPerWG;
+    const uint32_t n_tiles = (n + 31) / 32;
+    auto blk = [&](int b) {  // fresh LDS read at every use (see k_mlp_forward)
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return P::load_block(lds + (size_t)b * block_bytes<P>(), l);
+    };
+    auto bias = [&](int tile) {
+        int hh = h;
+        asm volatile("" : "+v"(hh));
+        return bias_tile(biasT, tile, hh);
+    };
+    const uint32_t last_plane = din / 2 - 1;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const size_t row = (size_t)tile * 32 + p;
+        KB X;
+        if constexpr (HP) {
+            uint32_t u[8];
+            load_rows_half_g(x, row, n, h, x_planes, last_plane, u);
+            X = rows_kb_half<P>(u);
+        } else {
+            float raw[16];
+            load_rows_raw_g(x, row, n, h, x_planes, din, raw);
+            X = rows_kb<P>(raw);
+        }
+        KB H1[NTH], HL[NTH];
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = bias(t);
+            P::mma(acc, blk(B::W1 + t), X);
+            H1[t] = P::relu(acc);
+        }
+        if constexpr (LAYERS == 3) {
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                f32x16 acc = bias(NTH + t);
+#pragma unroll
+                for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B::W2 + t * NTH + tk), H1[tk]);
+                HL[t] = P::relu(acc);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) HL[t] = H1[t];
+        }
+        f32x16 acc = bias(2 * NTH);
+#pragma unroll
+        for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B::W3 + tk), HL[tk]);
+        if (row < n && h == 0) {
+            f32x4 o = {P::round(acc[0]), P::round(acc[1]), P::round(acc[2]), P::round(acc[3])};
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(out + row * DOUT));
+        }
+    }
+}
+
+template <class P, int NTH, int LAYERS, bool HP>
+__global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float *__restrict__ x, uint32_t x_planes,
+                                                                        const float *__restrict__ dout, uint32_t n,
+                                                                        uint32_t din, Weights w, float *__restrict__ dx,
+                                                                        uint32_t dx_planes, Grads g) {
+    using B = Blk<NTH, LAYERS>;
+    using KB = typename P::KB;
+    constexpr int H = 32 * NTH;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *biasT = reinterpret_cast<float *>(lds + (size_t)B::ALL_COUNT * block_bytes<P>());
+    build_blocks_g<P, NTH, LAYERS>(lds, biasT, w, (int)din, B::ALL_COUNT);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), p = lane & 31, h = lane >> 5;
+    const uint32_t wave = blockIdx.x * kWavesPerWG + threadIdx.x / kWave, n_waves = gridDim.x * kWavesPerWG;
+    const uint32_t n_tiles = (n + 31) / 32;
+    // the lane offsets are laundered through an empty asm ONCE PER TILE: every tile re-reads its operand blocks from
+    // LDS (hipcc would otherwise hoist the loop-invariant blocks into registers and spill), at one move per tile
+    int lt = lane, ht = h;
+    auto blk = [&](int b) { return P::load_block(lds + (size_t)b * block_bytes<P>(), lt); };
+    auto blk_fresh = [&](int b) {  // the identity blocks serve seven products per tile: re-read at every use (8 registers)
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return P::load_block(lds + (size_t)b * block_bytes<P>(), l);
+    };
+    auto bias = [&](int tile) { return bias_tile(biasT, tile, ht); };
+    // a tile held "lane = sample" times an identity block = the same tile held "lane = index" (exact: one non-zero
+    // product per output)
+    auto transpose = [&](const KB &a, int id_block) {
+        f32x16 t = splat(0.f);
+        P::mma(t, a, blk_fresh(id_block));
+        return P::cast(t);
+    };
+    const uint32_t last_plane = din / 2 - 1;
+
+    // weight-gradient tiles: lane = column (input-side feature), register q = row rowmap(q, h) (output-side feature)
+    f32x16 gW1[NTH], gW2[NTH][NTH], gW3[NTH];
+    float gb1[NTH], gb2[NTH], gb3 = 0.f;
+#pragma unroll
+    for (int a = 0; a < NTH; ++a) {
+        gW1[a] = splat(0.f); gW3[a] = splat(0.f); gb1[a] = 0.f; gb2[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NTH; ++b) gW2[a][b] = splat(0.f);
+    }
+
+    // the NEXT tile's rows are requested before this tile's products start (the second wave of the SIMD hides issue
+    // gaps, not a memory round trip per tile)
+    float raw[HP ? 1 : 16];
+    uint32_t rawh[HP ? 8 : 1];
+    f32x4 dor;
+    {
+        const size_t r0 = (size_t)wave * 32 + p;
+        if constexpr (HP) load_rows_half_g(x, r0, n, h, x_planes, last_plane, rawh);
+        else load_rows_raw_g(x, r0, n, h, x_planes, din, raw);
+        dor = load_dout_raw(dout, r0, n);
+    }
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const size_t row = (size_t)tile * 32 + p;
+        const bool valid = row < n;
+        // the plane strides are laundered per iteration: hipcc otherwise keeps one 64-bit base pointer per plane and lane
+        // alive across the loop (32 registers; they were what spilled) instead of two adds per access
+        uint32_t xp = x_planes, dxp = dx_planes;
+        asm volatile("" : "+s"(xp), "+s"(dxp), "+v"(lt), "+v"(ht));
+        KB X;
+        if constexpr (HP) X = rows_kb_half<P>(rawh);
+        else X = rows_kb<P>(raw);
+        const KB dO = dout_kb<P>(dor, valid && h == 0);
+        if (tile + n_waves < n_tiles) {
+            const size_t rn = ((size_t)tile + n_waves) * 32 + p;
+            if constexpr (HP) load_rows_half_g(x, rn, n, h, xp, last_plane, rawh);
+            else load_rows_raw_g(x, rn, n, h, xp, din, raw);
+            dor = load_dout_raw(dout, rn, n);
+        }
+        // ---- forward recompute, lane = sample (the activations double as their own ReLU masks).  The order below keeps
+        // the live set small (it is what decides spills at 256 registers): every orientation-1 tile is transposed
+        // as soon as its last orientation-1 use is over, and the hidden-1 gradient is formed directly in orientation 2,
+        // where its mask (the transposed activations) already is.
+        KB H1p[NTH], HL[NTH];
+        {
+            KB H1[NTH];
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                f32x16 acc = bias(t);
+                P::mma(acc, blk(B::W1 + t), X);
+                H1[t] = P::relu(acc);
+            }
+            if constexpr (LAYERS == 3) {
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) {
+                    f32x16 acc = bias(NTH + t);
+#pragma unroll
+                    for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B::W2 + t * NTH + tk), H1[tk]);
+                    HL[t] = P::relu(acc);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) HL[t] = H1[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) H1p[t] = transpose(H1[t], B::IDD);  // lane = hidden-1 feature, values = samples
+        }
+        // ---- gradient wrt the last hidden layer (lane = sample); dW_last and db_last from the transposed operands
+        KB dHL[NTH];
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) {
+            f32x16 acc = splat(0.f);
+            P::mma_lo(acc, blk(B::W3T + t), dO);
+            dHL[t] = P::masked(acc, HL[t]);
+        }
+        {
+            f32x16 tO = splat(0.f);
+            P::mma_lo(tO, dO, blk_fresh(B::IDX));
+            const KB dOp = P::cast(tO);  // lane = output index, values = the tile's samples
+            gb3 += P::sum(dOp);
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                const KB HLp = LAYERS == 3 ? transpose(HL[t], B::IDD) : H1p[t];
+                P::mma(gW3[t], dOp, HLp);   // dW_last[o][f] += sum_s dO[s][o] H_last[s][f]
+            }
+        }
+        KB dH1p[NTH];  // lane = hidden-1 feature, values = samples
+        if constexpr (LAYERS == 3) {
+#pragma unroll
+            for (int ti = 0; ti < NTH; ++ti) {   // dW2[i][j] += sum_s dH2[s][i] H1[s][j]
+                const KB dHLp = transpose(dHL[ti], B::IDD);
+                gb2[ti] += P::sum(dHLp);
+#pragma unroll
+                for (int tj = 0; tj < NTH; ++tj) P::mma(gW2[ti][tj], dHLp, H1p[tj]);
+            }
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {      // dH1[s][f1] = relu'(.) sum_f2 dH2[s][f2] W2[f2][f1], output lane = f1
+                f32x16 acc = splat(0.f);
+#pragma unroll
+                for (int tk = 0; tk < NTH; ++tk) P::mma(acc, dHL[tk], blk(B::W2T + t * NTH + tk));
+                dH1p[t] = P::masked(acc, H1p[t]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) dH1p[t] = transpose(dHL[t], B::IDD);
+        }
+        {   // dW1[i][j] += sum_s dH1[s][i] X[s][j]
+            const KB Xp = transpose(X, B::IDX);
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                gb1[t] += P::sum(dH1p[t]);
+                P::mma(gW1[t], dH1p[t], Xp);
+            }
+        }
+        {   // ---- input gradient dX = W1^T dH1, lane = sample again
+            f32x16 acc = splat(0.f);
+#pragma unroll
+            for (int tk = 0; tk < NTH; ++tk) {
+                const KB dH1 = LAYERS == 3 ? transpose(dH1p[tk], B::IDD) : dHL[tk];
+                P::mma(acc, blk(B::W1T + tk), dH1);
+            }
+            const bool full = din == (uint32_t)DIN;  // uniform: the usual width stores without per-plane guards
+            if constexpr (HP) {
+            if (valid) {
+                // binary16 planes: one 4-byte store per (level, row); this IS the rounding torch.autocast gives the
+                // input gradient of the first nn.Linear (a binary16 GEMM output)
+                uint32_t *dxh = reinterpret_cast<uint32_t *>(dx) + row;
+                uint32_t pk[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pk[2 * c] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){acc[4 * c], acc[4 * c + 1]}, half2v));
+                    pk[2 * c + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){acc[4 * c + 2], acc[4 * c + 3]}, half2v));
+                }
+                if (full) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dxh[(size_t)(4 * c + 2 * h) * dxp] = pk[2 * c];
+                        dxh[(size_t)(4 * c + 2 * h + 1) * dxp] = pk[2 * c + 1];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t lvl = 4 * c + 2 * h;
+                        if (lvl <= last_plane) dxh[(size_t)lvl * dxp] = pk[2 * c];
+                        if (lvl + 1 <= last_plane) dxh[(size_t)(lvl + 1) * dxp] = pk[2 * c + 1];
+                    }
+                }
+            }
+            } else {
+            if (valid && !dxp) {  // register q = input feature rowmap(q, h): four runs of four features
+                if (full) {
+                    float *dst = dx + row * DIN + 4 * h;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 o = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 8 * c));
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if ((uint32_t)rowmap(q, h) < din) dx[row * din + rowmap(q, h)] = acc[q];
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x2 a = {acc[4 * c], acc[4 * c + 1]}, b = {acc[4 * c + 2], acc[4 * c + 3]};
+                    const uint32_t lvl = 4 * c + 2 * h;
+                    if (lvl <= last_plane)
+                        __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dx + ((size_t)lvl * dxp + row) * 2));
+                    if (lvl + 1 <= last_plane)
+                        __builtin_nontemporal_store(b, reinterpret_cast<f32x2 *>(dx + ((size_t)(lvl + 1) * dxp + row) * 2));
+                }
+            }
+            }
+        }
+    }
+
+    // ---- reduce the weight gradients across the workgroup in LDS, then one atomic per element per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);
+    const int OFF_W1 = 0, OFF_B1 = OFF_W1 + H * (int)din, OFF_W2 = OFF_B1 + H,
+              OFF_B2 = OFF_W2 + (LAYERS == 3 ? H * H : 0), OFF_W3 = OFF_B2 + (LAYERS == 3 ? H : 0),
+              OFF_B3 = OFF_W3 + DOUT * H, TOTAL = OFF_B3 + DOUT;
+    for (int e = threadIdx.x; e < TOTAL; e += blockDim.x) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = rowmap(q, h);
+#pragma unroll
+        for (int ti = 0; ti < NTH; ++ti) {
+            if (p < (int)din) atomicAdd(&red[OFF_W1 + (32 * ti + r) * (int)din + p], gW1[ti][q]);
+            if constexpr (LAYERS == 3) {
+#pragma unroll
+                for (int tj = 0; tj < NTH; ++tj) atomicAdd(&red[OFF_W2 + (32 * ti + r) * H + 32 * tj + p], gW2[ti][tj][q]);
+            }
+            if (r < DOUT) atomicAdd(&red[OFF_W3 + r * H + 32 * ti + p], gW3[ti][q]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+        atomicAdd(&red[OFF_B1 + 32 * t + p], gb1[t]);
+        if constexpr (LAYERS == 3) atomicAdd(&red[OFF_B2 + 32 * t + p], gb2[t]);
+    }
+    if (p < DOUT) atomicAdd(&red[OFF_B3 + p], gb3);
+    __syncthreads();
+    for (int e = threadIdx.x; e < TOTAL; e += blockDim.x) {
+        const float v = red[e];
+        float *dst = e < OFF_B1 ? g.dW1 + (e - OFF_W1)
+                   : e < OFF_W2 ? g.db1 + (e - OFF_B1)
+                   : e < OFF_B2 ? g.dW2 + (e - OFF_W2)
+                   : e < OFF_W3 ? g.db2 + (e - OFF_B2)
+                   : e < OFF_B3 ? g.dW3 + (e - OFF_W3)
+                                : g.db3 + (e - OFF_B3);
+        if (v != 0.f) unsafeAtomicAdd(dst, v);
+    }
+}
+
 // ---------------------------------------------------------------- field head (elementwise, one thread per sample)
 // sigma, albedo and the two finite-difference normals from the MLP output of the P = 7 or 13 stencil points
 // (network_tcnn.py:94-138, activation.py:5-18, nerf/utils.py:47-48) in one pass instead of ~40 elementwise launches
@@ -930,16 +1375,44 @@ HeadArgs make_head_args(const float *x, const float *x2, const float *offsets_ho
 template <class P> constexpr size_t lds_bytes(int n_blocks) {
     return (size_t)n_blocks * block_bytes<P>() + (HID + HID + 32) * sizeof(float);
 }
+template <class P> constexpr size_t lds_bytes_g(int n_blocks, int bias_tiles) {
+    return (size_t)n_blocks * block_bytes<P>() + (size_t)bias_tiles * 32 * sizeof(float);
+}
 
-int grid_for(uint32_t n) {
+int grid_for(uint32_t n, int wgs_per_cu) {
     const uint32_t tiles = (n + 31) / 32, wgs = (tiles + kWavesPerWG - 1) / kWavesPerWG;
-    const uint32_t cap = 256 * (uint32_t)MI3D_TUNE(MI3D_T_MLP_WGS_PER_CU, 2);  // persistent: two workgroups per CU
+    const uint32_t cap = 256 * (uint32_t)wgs_per_cu;  // persistent beyond that many workgroups per CU
     return (int)(wgs < cap ? (wgs ? wgs : 1) : cap);
 }
 
+// network_tcnn.py:13-32: dim_in = 2 x levels (even, <= 32), hidden 32 or 64, 4 outputs, 2 or 3 layers
 bool dims_ok(uint32_t di, uint32_t dh, uint32_t dout, uint32_t layers) {
-    return di == DIN && dh == HID && dout == DOUT && layers == 3;
+    return di >= 2 && di <= (uint32_t)DIN && di % 2 == 0 && (dh == 32 || dh == 64) && dout == DOUT &&
+           (layers == 2 || layers == 3);
 }
+
+template <class P, int NTH, int LAYERS, bool HP>
+void launch_fwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, uint32_t n, uint32_t din, const Weights &w,
+                float *out) {
+    using B = Blk<NTH, LAYERS>;
+    hipLaunchKernelGGL((k_mlp_fwd_g<P, NTH, LAYERS, HP>), grid, dim3(kWave * kWavesPerWG),
+                       lds_bytes_g<P>(B::FWD_COUNT, B::BIAS_TILES), st, x, x_planes, n, din, w, out);
+}
+template <class P, int NTH, int LAYERS, bool HP>
+void launch_bwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, const float *dout, uint32_t n, uint32_t din,
+                const Weights &w, float *dx, uint32_t dx_planes, const Grads &g) {
+    using B = Blk<NTH, LAYERS>;
+    hipLaunchKernelGGL((k_mlp_bwd_g<P, NTH, LAYERS, HP>), grid, dim3(kWave * kWavesPerWG),
+                       lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
+}
+// runtime (hidden width, layer count) -> the template instance
+#define MI3D_MLP_DISPATCH(FN, P, HP, nth, layers, ...)                     \
+    do {                                                                   \
+        if ((nth) == 2 && (layers) == 3) FN<P, 2, 3, HP>(__VA_ARGS__);     \
+        else if ((nth) == 2) FN<P, 2, 2, HP>(__VA_ARGS__);                 \
+        else if ((layers) == 3) FN<P, 1, 3, HP>(__VA_ARGS__);              \
+        else FN<P, 1, 2, HP>(__VA_ARGS__);                                 \
+    } while (0)
 
 }  // namespace
 
@@ -952,18 +1425,32 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
 int mi3d_mlp_forward(const void *xv, uint32_t x_plane_rows, int planes_half, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream) {
-    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
-        (planes_half && (x_plane_rows == 0 || !half_mode)))
+    const uint32_t layers = (W2 == nullptr && b2 == nullptr) ? 2u : 3u;
+    if (!dims_ok(dim_in, dim_hidden, dim_out, layers) || (x_plane_rows != 0 && x_plane_rows < n) ||
+        (planes_half && (x_plane_rows == 0 || !half_mode)) || W1 == nullptr || b1 == nullptr || W3 == nullptr ||
+        b3 == nullptr || (layers == 3 && (W2 == nullptr || b2 == nullptr)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const float *x = reinterpret_cast<const float *>(xv);
     const Weights w{W1, b1, W2, b2, W3, b3};
-    if (half_mode)
-        hipLaunchKernelGGL(k_mlp_forward<F16>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F16>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, planes_half, n, w, out);
-    else
-        hipLaunchKernelGGL(k_mlp_forward<F32>, dim3(grid_for(n)), dim3(kWave * kWavesPerWG),
-                           lds_bytes<F32>(B_FWD_COUNT), as_stream(stream), x, x_plane_rows, planes_half, n, w, out);
+    const int nth = (int)dim_hidden / 32;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(grid_for(n, MI3D_TUNE(MI3D_T_MLP_FWD_WGS_PER_CU, 5)));
+#ifdef MI3D_DEV
+    if (MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0) == 3 && nth == 2 && layers == 3 && dim_in == (uint32_t)DIN) {  // round 2's kernel
+        const dim3 g2(grid_for(n, 2));
+        if (half_mode)
+            hipLaunchKernelGGL(k_mlp_forward<F16>, g2, dim3(kWave * kWavesPerWG), lds_bytes<F16>(B_FWD_COUNT), st, x,
+                               x_plane_rows, planes_half, n, w, out);
+        else
+            hipLaunchKernelGGL(k_mlp_forward<F32>, g2, dim3(kWave * kWavesPerWG), lds_bytes<F32>(B_FWD_COUNT), st, x,
+                               x_plane_rows, planes_half, n, w, out);
+        return (int)hipGetLastError();
+    }
+#endif
+    if (half_mode && planes_half) MI3D_MLP_DISPATCH(launch_fwd, F16, true, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
+    else if (half_mode) MI3D_MLP_DISPATCH(launch_fwd, F16, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
+    else MI3D_MLP_DISPATCH(launch_fwd, F32, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
     return (int)hipGetLastError();
 }
 
@@ -971,34 +1458,42 @@ int mi3d_mlp_backward(const void *xv, uint32_t x_plane_rows, int planes_half, co
                       const float *W2, const float *b2, const float *W3, const float *b3, uint32_t dim_in,
                       uint32_t dim_hidden, uint32_t dim_out, int half_mode, void *dxv, uint32_t dx_plane_rows, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3,
                       void *stream) {
-    if (!dims_ok(dim_in, dim_hidden, dim_out, 3) || (x_plane_rows != 0 && x_plane_rows < n) ||
+    const uint32_t layers = (W2 == nullptr && b2 == nullptr) ? 2u : 3u;
+    if (!dims_ok(dim_in, dim_hidden, dim_out, layers) || (x_plane_rows != 0 && x_plane_rows < n) ||
         (dx_plane_rows != 0 && dx_plane_rows < n) ||
-        (planes_half && (x_plane_rows == 0 || dx_plane_rows == 0 || !half_mode)))
+        (planes_half && (x_plane_rows == 0 || dx_plane_rows == 0 || !half_mode)) || W1 == nullptr || b1 == nullptr ||
+        W3 == nullptr || b3 == nullptr || dW1 == nullptr || db1 == nullptr || dW3 == nullptr || db3 == nullptr ||
+        (layers == 3 && (W2 == nullptr || b2 == nullptr || dW2 == nullptr || db2 == nullptr)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const float *x = reinterpret_cast<const float *>(xv);
     float *dx = reinterpret_cast<float *>(dxv);
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
-    const dim3 grid(grid_for(n)), block(kWave * kWavesPerWG);
+    const int nth = (int)dim_hidden / 32;
+    const dim3 grid(grid_for(n, MI3D_TUNE(MI3D_T_MLP_WGS_PER_CU, 2))), block(kWave * kWavesPerWG);
     hipStream_t st = as_stream(stream);
+    const bool classic = nth == 2 && layers == 3 && dim_in == (uint32_t)DIN;
 #ifdef MI3D_DEV
-    const int variant = MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0);
-    if (half_mode && variant == 1 && !planes_half) {  // one tile at a time
-        hipLaunchKernelGGL((k_mlp_backward<F16, 1, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows,
-                           0, dout, n, w, dx, dx_plane_rows, g);
+    if (half_mode && classic && MI3D_TUNE(MI3D_T_MLP_BWD_VARIANT, 0) == 3) {  // round 2's kernel (one wave per SIMD, staged)
+        if (planes_half)
+            hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 1,
+                               dout, n, w, dx, dx_plane_rows, g);
+        else
+            hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 0,
+                               dout, n, w, dx, dx_plane_rows, g);
         return (int)hipGetLastError();
     }
 #endif
     if (half_mode && planes_half)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, true>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 1,
-                           dout, n, w, dx, dx_plane_rows, g);
+        MI3D_MLP_DISPATCH(launch_bwd, F16, true, nth, layers, grid, st, x, x_plane_rows, dout, n, dim_in, w, dx, dx_plane_rows, g);
     else if (half_mode)
-        hipLaunchKernelGGL((k_mlp_backward<F16, 2, 1, false>), grid, block, lds_bytes<F16>(B_ALL_COUNT), st, x, x_plane_rows, 0,
-                           dout, n, w, dx, dx_plane_rows, g);
-    else
+        MI3D_MLP_DISPATCH(launch_bwd, F16, false, nth, layers, grid, st, x, x_plane_rows, dout, n, dim_in, w, dx, dx_plane_rows, g);
+    else if (classic)   // exact fp32 at full width: 16-register K-blocks do not fit two waves per SIMD - one wave, one tile
         hipLaunchKernelGGL((k_mlp_backward<F32, 1, 1, false>), grid, block, lds_bytes<F32>(B_ALL_COUNT), st, x, x_plane_rows, 0,
                            dout, n, w, dx, dx_plane_rows, g);
+    else
+        MI3D_MLP_DISPATCH(launch_bwd, F32, false, nth, layers, grid, st, x, x_plane_rows, dout, n, dim_in, w, dx, dx_plane_rows, g);
     return (int)hipGetLastError();
 }
 

@@ -689,15 +689,18 @@ __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel
                                             float g0, float g1, uint32_t *fill, BinRecord *__restrict__ arena,
                                             float *__restrict__ grad_table, float &lmax) {
     const uint32_t b = e >> kBinShift;
-    const uint32_t slot = atomicAdd(&fill[plan.level_bin0[l] + b], 1u);  // wave-private LDS counter
-    // a non-finite contribution makes the level's maximum infinite: k_bin_reduce then poisons the level with NaN (the
-    // float atomics of the reference would have put the inf / NaN into the table)
+    // a non-finite contribution never enters the fixed-point path: it goes to the table with float atomics, which puts
+    // the inf / NaN on exactly the entries the reference's atomicAdd would have put it on (GradScaler then sees it)
     const bool finite = fabsf(g0) <= 3.4028234663852886e38f && fabsf(g1) <= 3.4028234663852886e38f;
-    lmax = finite ? fmaxf(lmax, fmaxf(fabsf(g0), fabsf(g1))) : __builtin_inff();
+    uint32_t slot = 0xFFFFFFFFu;
+    if (finite) {
+        slot = atomicAdd(&fill[plan.level_bin0[l] + b], 1u);  // wave-private LDS counter
+        lmax = fmaxf(lmax, fmaxf(fabsf(g0), fabsf(g1)));
+    }
     if (slot < plan.level_cap[l]) {
         BinRecord r{e, g0, g1};
         reinterpret_cast<BinRecord *>(reinterpret_cast<char *>(arena) + plan.level_base[l])[((size_t)gw * level_bins(L) + b) * plan.level_cap[l] + slot] = r;
-    } else {  // region full: straight to the table
+    } else {  // region full (or non-finite): straight to the table
         float *dst = grad_table + ((size_t)L.offset + e) * 2;
         unsafeAtomicAdd(dst, g0);
         unsafeAtomicAdd(dst + 1, g1);
@@ -835,9 +838,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
-                if (__ballot(bad) != 0ull) {  // inf / NaN in the tile: the level is poisoned by the reduce, nothing to sum
-                    lmax = __builtin_inff();
-                    dead = true;
+                if (__ballot(bad) != 0ull) {  // inf / NaN in the tile: its contributions go to the table one by one (float
+                    dead = true;              // atomics, as the reference adds them) instead of through the fixed-point sums
                 } else if (tmax > 0.f) {
                     int ex;
                     (void)frexpf(tmax, &ex);  // tmax < 2^ex
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                   (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                     : make_float2(__uint_as_float(r0), __uint_as_float(r1));
-                const bool has = valid && !dead && (d.x != 0.f || d.y != 0.f);
+                const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
                 float q[3];
@@ -922,10 +924,13 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     // the prime), the x + 1 entry derived from the x entry, the level's maximum taken from the gradient
                     // pair (every contribution is a weight <= 1 times it), a 32-bit index into this wave's regions.
                     if (has) {
+                        // a non-finite gradient pair: its contributions take the float-atomic path below (every put() of
+                        // this lane is refused), exactly the entries the reference's atomicAdd would have poisoned
                         const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
-                        lmax = finite ? fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y))) : __builtin_inff();  // inf / NaN -> inf
+                        if (finite) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
                         const float wyz[4] = {gy * gz, fy * gz, gy * fz, fy * fz};
                         auto put = [&](uint32_t e, uint32_t tt, float va, float vb, float vfx) {
+                            if (!finite) return false;
                             const uint32_t bin = e >> kBinShift;
                             const uint32_t slot = atomicAdd(&fill_l[bin], 1u);  // wave-private LDS counter
                             if (slot < cap) {
@@ -955,7 +960,9 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                                 e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
                             }
                             const float a = wyz[j] * d.x, b = wyz[j] * d.y;
-                            if ((e0 >> kBinShift) == (e1 >> kBinShift)) {
+                            // a pair record needs both entries in one bin AND derivable from each other: hashed e1 = e0 ^ flip
+                            // by construction, dense e1 = e0 + 1 (not where grid_entry wraps the +1 corner to entry 0)
+                            if ((e0 >> kBinShift) == (e1 >> kBinShift) && (L.hashed || e1 == e0 + 1u)) {
                                 if (!put(e0, t, a, b, fx)) { to_table(e0, gx * a, gx * b); to_table(e1, fx * a, fx * b); }
                             } else {  // the pair straddles two bins: two singles (fx = 0: only the header's entry receives (a, b))
                                 if (!put(e0, 0u, gx * a, gx * b, 0.f)) to_table(e0, gx * a, gx * b);
@@ -973,6 +980,17 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                         for (uint32_t k = 0; k < 8; ++k) {
                             const uint32_t e = grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2));
                             emit_record(plan, L, l, gw, e, wk[k] * d.x, wk[k] * d.y, fill, arena, grad_table, lmax);
+                        }
+                    }
+                    continue;
+                }
+                if (dead) {  // a tile with a non-finite gradient: plain float atomics, entry by entry
+                    if (has) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) {
+                            float *dst = grad_table + ((size_t)L.offset + grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))) * 2;
+                            unsafeAtomicAdd(dst, wk[k] * d.x);
+                            unsafeAtomicAdd(dst + 1, wk[k] * d.y);
                         }
                     }
                     continue;
@@ -1024,15 +1042,6 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
 
 constexpr int kReduceWaves = (int)kReduceWavesC;  // 1024-thread workgroups, one per CU: 128 KB of LDS accumulators each
 
-// A level that received a non-finite gradient: every entry of the bin becomes NaN, so that torch's GradScaler (and
-// anyone reading encoder.params.grad) sees the overflow exactly as it would after the reference's float atomics.
-__device__ __forceinline__ void poison_bin(const GridLevel &L, uint32_t lb, float *__restrict__ grad_table) {
-    const uint32_t e0 = lb * kBinEntries;
-    const uint32_t live = L.size - e0 < kBinEntries ? L.size - e0 : kBinEntries;
-    float *dst = grad_table + ((size_t)L.offset + e0) * 2;
-    for (uint32_t i = threadIdx.x; i < live * 2; i += blockDim.x) dst[i] = __builtin_nanf("");
-}
-
 // Every record value is scaled by a power of two 2^k chosen from the largest |value| any wave emitted for the level
 // (|v| 2^k < 2^38, so 2^24 records cannot overflow), rounded to an integer and added with ds_add_u64.  The scaling is
 // exact; what is dropped is whatever lies more than 38 binary digits below the level's largest contribution - far
@@ -1068,7 +1077,6 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
         __syncthreads();
         m = 0.f;
         for (int w = 0; w < kReduceWaves; ++w) m = fmaxf(m, wg_max[w]);
-        if (m > 3.0e38f) { poison_bin(T.level[lvl], lb, grad_table); return; }  // an inf / NaN record was emitted
         if (!(m > 0.f)) return;  // nothing but zeros was emitted for this level (uniform across the workgroup)
         int e;
         (void)frexpf(m, &e);  // m < 2^e

@@ -21,24 +21,31 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import grid_ops
+from . import mlp_ops
 
-# Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples
-# (180 GiB for the 10.9 M samples x 13 points of BASELINE config 2), so samples are processed in slices that fit;
-# 120 GiB lets config 2 go in two.  It is a plain torch allocation made per call: the caching allocator
-# hands the same block back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
-WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "120")) * (1 << 30))
+# Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples, so
+# the samples are processed in slices that fit (mi3d_grid_scatter_binned halves the slice until its plan fits the
+# workspace it is handed).  It is a plain torch allocation made per call: the caching allocator hands the same block
+# back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
+WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "32")) * (1 << 30))
 
 
 def scatter_workspace(device, needed, cap=None):
-    """uint8 scratch of min(needed, cap, 45 % of the device's memory) bytes from torch's caching allocator (or None).
-    The request is rounded up to a whole GiB so that the sample count drifting from step to step does not leave the
-    caching allocator with a trail of slightly different multi-GiB blocks (measured: 2 slices of 120 GiB cost 75 ms per
-    141 M evaluations, 4 slices of 60 GiB 80 ms)."""
+    """uint8 scratch of min(needed, cap, 80 % of what the device can still give) bytes from torch's caching allocator,
+    halving on an allocation failure; None when nothing useful can be had (the scatter then takes its all-atomic path).
+    Requests are whole GiB so that the sample count drifting from step to step does not leave the caching allocator with
+    a trail of slightly different multi-GiB blocks."""
     cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
-    total = torch.cuda.get_device_properties(device).total_memory
     gib = 1 << 30
-    want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(total * 0.45))
-    return torch.empty(want, dtype=torch.uint8, device=device) if want > 0 else None
+    free, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # torch can re-use this itself
+    want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(0.8 * (free + cached)))
+    while want >= (64 << 20):
+        try:
+            return torch.empty(want, dtype=torch.uint8, device=device)
+        except torch.cuda.OutOfMemoryError:
+            want //= 2
+    return None
 
 
 def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None):
@@ -96,11 +103,14 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
     rows, plane_rows = P_active * n, feats.shape[1]
     # binary16 gradient planes under autocast: what the reference's binary16 dgrad GEMM hands the encoder's backward
     dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=feats.dtype, device=x.device)
-    grads = [torch.zeros_like(t) for t in ws]
+    grads = [None if t is None else torch.zeros_like(t) for t in ws]
     grid_ops._timed("mlp_bwd", lambda: L.call(
         "mi3d_mlp_backward", L.ptr(feats), plane_rows, int(feats.dtype == torch.float16), L.ptr(dh), rows,
         *[L.ptr(t) for t in ws], *dims, int(half_mode),
         L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream(x)), rows)
+    if grid_ops.CENSUS is not None:  # bench.py, one untimed step: which gradient pairs are non-zero, per level
+        nz = torch.stack([(dplanes[l] != 0).any(-1).sum() for l in range(dplanes.shape[0])])
+        grid_ops.CENSUS.append({"P_active": int(P_active), "rows": int(rows), "nonzero_pairs_per_level": nz})
     gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
                         n_params)
     return gp, grads
@@ -116,7 +126,7 @@ class _FieldStencil(Function):
         if x2 is not None:
             x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
         params = L.dev_f32(params, "params")
-        ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
+        ws = mlp_ops._weights((W1, b1, W2, b2, W3, b3))
         offs, offs_p = grid_ops._offs_arg(offsets)
         with L.on(x):
             feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step)
@@ -145,13 +155,12 @@ def _half_mode(half_mode):
 
 def field_stencil(params, layers, x, offsets, cfg, bound=1.0, x2=None, P0=None, step=0.0, half_mode=None):
     """h [P*n, 4] (row = point*n + sample): the MLP output at clamp(base + offsets[p]) for every sample, differentiable
-    w.r.t. the hash table and the MLP weights.  `layers`: the three nn.Linear modules of sigma_net."""
+    w.r.t. the hash table and the MLP weights.  `layers`: the two or three nn.Linear modules of sigma_net."""
     P = np.asarray(offsets).reshape(-1, 3).shape[0]
     if P0 is None:
         P0 = P
-    l1, l2, l3 = layers
-    return _FieldStencil.apply(params, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, x, x2, offsets, P0,
-                               bound, cfg, step, _half_mode(half_mode))
+    return _FieldStencil.apply(params, *mlp_ops.layer_args(layers), x, x2, offsets, P0, bound, cfg, step,
+                               _half_mode(half_mode))
 
 
 def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon):
@@ -246,7 +255,7 @@ class _Field(Function):
         if x2 is not None:
             x2 = L.dev_f32(x2.contiguous().view(-1, 3), "x2", 3)
         params = L.dev_f32(params, "params")
-        ws = [L.dev_f32(t.contiguous(), "weight") for t in (W1, b1, W2, b2, W3, b3)]
+        ws = mlp_ops._weights((W1, b1, W2, b2, W3, b3))
         offs, offs_p = grid_ops._offs_arg(offsets)
         if offs.shape[0] not in (7, 13):
             raise L.Mi3dError("the fused field takes the 7- or 13-point stencil")
@@ -286,7 +295,6 @@ def field(params, layers, x, offsets, cfg, bound, blob_density, blob_radius, x2=
     P = np.asarray(offsets).reshape(-1, 3).shape[0]
     if P0 is None:
         P0 = P
-    l1, l2, l3 = layers
-    out = _Field.apply(params, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, x, x2, offsets, P0, bound,
-                       cfg, step, _half_mode(half_mode), blob_density, blob_radius, epsilon)
+    out = _Field.apply(params, *mlp_ops.layer_args(layers), x, x2, offsets, P0, bound, cfg, step,
+                       _half_mode(half_mode), blob_density, blob_radius, epsilon)
     return out if len(out) == 4 else (*out, None)

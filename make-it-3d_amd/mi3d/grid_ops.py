@@ -1,5 +1,6 @@
 """Stencil-aware hash-grid encode (autograd): all P evaluation points of every sample in one launch, backward through
 the request-minimising scatter of csrc/hashgrid.hip (Part 3 of include/mi3d.h)."""
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -24,6 +25,27 @@ def stencil_offsets(center=True, second=False):
 # bench.py sets this to {"scatter": [], "encode": []} to collect HIP-event pairs around the two grid kernels
 # (events are recorded on torch's current stream, the stream the C ABI launches on).
 PROFILE = None
+
+
+# bench.py sets this to a list to collect, for every binned scatter of ONE untimed step, the fraction of (row, level)
+# gradient pairs that are not exactly zero (the emit skips the others, as the reference's atomics add zeros).
+CENSUS = None
+
+
+@contextlib.contextmanager
+def phase(kind):
+    """HIP-event pair around a whole phase of the step (render, guidance, backward, optimizer): bench.py's
+    phases_ms_per_step.  A no-op unless bench.py collects."""
+    if PROFILE is None:
+        yield
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    try:
+        yield
+    finally:
+        e1.record()
+        PROFILE.setdefault("phase:" + kind, []).append((e0, e1))
 
 
 def _timed(kind, launch, evals):
@@ -56,7 +78,7 @@ class _EncodePoints(Function):
         if count is not None:  # rows past *count are not written by the kernel
             out.zero_()
         with L.on(x):
-            _timed("encode", lambda: L.call(
+            _timed("encode_rows", lambda: L.call(
                 "mi3d_grid_encode_points", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
                 L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"],
                 cfg["log2_hashmap_size"], L.ptr(out), L.stream(x)), n * P)
@@ -73,7 +95,7 @@ class _EncodePoints(Function):
         grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
         _, offs_p = _offs_arg(offs)
         with L.on(x):
-            _timed("scatter", lambda: L.call(
+            _timed("scatter_rows", lambda: L.call(
                 "mi3d_grid_scatter_points", L.ptr(x), L.ptr(x2 if has_x2 else None), x.shape[0],
                 L.ptr(count if has_count else None), offs_p, P0, offs.shape[0], bound, L.ptr(dout), cfg["n_levels"],
                 cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], step, L.ptr(grad),

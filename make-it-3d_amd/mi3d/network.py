@@ -49,14 +49,20 @@ class MLP(nn.Module):
             for l in range(num_layers)])
 
     def fused_ok(self, x):
-        """The matrix-core kernel covers the shape network_tcnn.py:67 builds (32 -> 64 -> 64 -> 4, biased)."""
+        """The matrix-core kernels cover every shape network_tcnn.py:37-45,67 can build around this field: input width
+        2 x levels <= 32, hidden 32 or 64, 2 or 3 layers, 4 outputs, biased (csrc/field.hip: k_mlp_fwd_g / k_mlp_bwd_g)."""
         return (x.is_cuda and all(l.bias is not None for l in self.net)
                 and mlp_ops.supported(self.dim_in, self.dim_hidden, self.dim_out, self.num_layers))
 
     def forward(self, x):
         if self.fused_ok(x):
             return mlp_ops.fused_mlp(x, self.net)
-        for l, layer in enumerate(self.net):  # other shapes (e.g. BASELINE config 1's 8 -> 32 -> 4): library GEMMs
+        if x.is_cuda:  # no eager path on the GPU: a shape the kernels do not cover is an error, not a silent library GEMM
+            raise mlp_ops.L.Mi3dError(
+                f"MLP {self.dim_in} -> {self.num_layers - 1} x {self.dim_hidden} -> {self.dim_out} (bias "
+                f"{all(l.bias is not None for l in self.net)}) is not covered by the matrix-core kernels "
+                f"(dim_in even and <= 32, hidden 32 or 64, 2 or 3 layers, 4 outputs, biased)")
+        for l, layer in enumerate(self.net):  # CPU tensors only: the host-side tests of the module surface
             x = layer(x)
             if l != self.num_layers - 1:
                 x = F.relu(x, inplace=True)

@@ -170,15 +170,27 @@ def refine_render(unet, points, feats, world2cam, focal, H, W, radius, ppp):
 
 
 def refine_train_step(unet, params, optimizer, guidance, text_z, points, world2cam, focal, H, W, radius, ppp,
-                      colour_origin, guidance_scale=5.0, t=None):
-    """One novel-view iteration of nerf/utils.py:839-894.  params = dict(colour [P,3], feat [P,16]) (nn.Parameters)."""
+                      colour_origin, guidance_scale=5.0, t=None, clip_model=None, ref_rgb=None, ref_text=None):
+    """One novel-view iteration of nerf/utils.py:839-894.  params = dict(colour [P,3], feat [P,16]) (nn.Parameters).
+
+    `clip_model`, `ref_rgb`, `ref_text` are what the reference hands the guidance (utils.py:878-879): with them, a draw
+    of t <= 400 takes the guidance's denoise + CLIP branch and its loss VALUE joins `loss` as `clip_loss` does there (it
+    carries no gradient: the reference decodes under no_grad).  Without a CLIP model that branch cannot
+    run, so t is then drawn from the SDS part of the guidance's range only instead of raising mid-training.  The
+    trainer-level CLIP / contextual terms of utils.py:880-883 need weights that do not exist offline (out of
+    scope)."""
     feats = torch.cat((params["colour"], params["feat"]), -1).float()
     rgb, mask = refine_render(unet, points, feats, world2cam, focal, H, W, radius, ppp)
+    have_clip = clip_model is not None and ref_rgb is not None and ref_text is not None
+    if t is None and not have_clip:
+        lo = max(guidance.min_step, int(0.4 * guidance.num_train_timesteps) + 1)   # sd.py:153: t/1000 <= 0.4 -> CLIP branch
+        t = int(torch.randint(lo, max(lo, guidance.max_step) + 1, [1]).item())
     # sd.py:171 injects the SDS gradient with latents.backward(retain_graph=True) INSIDE train_step ...
-    guidance.train_step(text_z, rgb, guidance_scale=guidance_scale, t=t)
+    clip_loss, _ = guidance.train_step(text_z, rgb, ref_rgb=ref_rgb, islarge=False, ref_text=ref_text,
+                                       clip_model=clip_model, guidance_scale=guidance_scale, t=t)
     bg_loss = 1e-3 * (1 - rgb * (1 - mask)).sum()
     reg_loss = F.mse_loss(params["colour"], colour_origin) * 1e3
-    loss = reg_loss + bg_loss
+    loss = clip_loss + reg_loss + bg_loss
     # ... and the reference then zeroes the gradients before its own backward (nerf/utils.py:888-890): on the SDS
     # branch the guidance gradient never reaches the optimiser.  Kept as the reference has it - the work is the same.
     optimizer.zero_grad()

@@ -229,7 +229,7 @@ class NeRFRenderer(nn.Module):
             noises = torch.rand(N, dtype=torch.float32, device=device) if perturb else None
             ctl, alive = raymarching.infer_begin(N, device, align)
             spare = torch.empty_like(alive)
-            n_ub, done_lb, rounds = N, 0, 0
+            n_ub, done_lb, since_sync, next_sync = N, 0, 0, sync_every
             while n_ub > 0 and done_lb < max_steps:
                 rows_ub = min(N, 8 * n_ub)
                 rows_ub += align - rows_ub % align       # >= the device's n_alive * n_step rounded past `align`
@@ -243,10 +243,13 @@ class NeRFRenderer(nn.Module):
                 raymarching.compact_alive_ctl(ctl, alive, spare, N, align, max_steps)
                 alive, spare = spare, alive
                 done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
-                rounds += 1
-                if rounds % sync_every == 0:
-                    state = ctl.tolist()                 # the only synchronisation: every `sync_every` rounds
-                    n_ub, done_lb = state[0], state[3]
+                since_sync += 1
+                if since_sync >= next_sync:
+                    state = ctl.tolist()                 # the only synchronisation
+                    # while rays are dying quickly the host's bound goes stale quickly (and every round evaluates the
+                    # field on its rows_ub rows): read the count back every round then, every `sync_every` otherwise
+                    next_sync = 1 if 4 * state[0] < 3 * n_ub else sync_every
+                    n_ub, done_lb, since_sync = state[0], state[3], 0
 
         if bg_color is None:
             bg_color = 1

@@ -59,31 +59,37 @@ def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, d
                    shading="albedo", ambient_ratio=1.0, sds_backward="single", t=None, grad_sync=None):
     """Returns the (unscaled) regulariser loss tensor.  `grad_sync` (callable or None) runs between backward and
     the optimizer step - the data-parallel all-reduce hook."""
+    from .grid_ops import phase
     optimizer.zero_grad(set_to_none=False)
     B = rays_o.shape[0]
     with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-        bg_color = torch.rand(3, device=rays_o.device)
-        outputs = model.render(rays_o, rays_d, depth_scale=depth_scale, bg_color=bg_color, staged=False, perturb=True,
-                               ambient_ratio=ambient_ratio, shading=shading, force_all_rays=True,
-                               **render_kwargs(opt))
-        pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
-        pred_ws = outputs["weights_sum"].reshape(B, 1, H, W)
-        if sds_backward == "reference":
-            guidance.train_step(text_z, pred_rgb, guidance_scale=opt.guidance_scale, t=t)  # NeRF backward #1
-            sds_term = None
-        else:
-            latents, grad = guidance.sds_gradient(text_z, pred_rgb, opt.guidance_scale, t)
-            sds_term = (latents.float() * grad.float()).sum()
-        loss = regularisers(opt, outputs, pred_ws)
-    total = scaler.scale(loss)
-    if sds_term is not None:
-        total = total + sds_term  # the SDS gradient is never loss-scaled (sd.py:171)
-    total.backward()
-    if grad_sync is not None:
-        grad_sync()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10)  # on still-scaled grads, as utils.py:984
-    scaler.step(optimizer)
-    scaler.update()
+        with phase("render_forward"):
+            bg_color = torch.rand(3, device=rays_o.device)
+            outputs = model.render(rays_o, rays_d, depth_scale=depth_scale, bg_color=bg_color, staged=False,
+                                   perturb=True, ambient_ratio=ambient_ratio, shading=shading, force_all_rays=True,
+                                   **render_kwargs(opt))
+            pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+            pred_ws = outputs["weights_sum"].reshape(B, 1, H, W)
+        with phase("guidance_train_step"):  # VAE encode + U-Net x2 (+ NeRF backward #1 in the reference schedule)
+            if sds_backward == "reference":
+                guidance.train_step(text_z, pred_rgb, guidance_scale=opt.guidance_scale, t=t)  # NeRF backward #1
+                sds_term = None
+            else:
+                latents, grad = guidance.sds_gradient(text_z, pred_rgb, opt.guidance_scale, t)
+                sds_term = (latents.float() * grad.float()).sum()
+        with phase("regularisers_backward"):
+            loss = regularisers(opt, outputs, pred_ws)
+    with phase("regularisers_backward"):
+        total = scaler.scale(loss)
+        if sds_term is not None:
+            total = total + sds_term  # the SDS gradient is never loss-scaled (sd.py:171)
+        total.backward()
+    with phase("sync_clip_optimizer"):
+        if grad_sync is not None:
+            grad_sync()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10)  # on still-scaled grads, as utils.py:984
+        scaler.step(optimizer)
+        scaler.update()
     return loss.detach()
 
 

@@ -121,9 +121,114 @@ def test_fp16_mode_matches_autocast(cuda, n):
     np.testing.assert_allclose(got[0].cpu().numpy(), h.cpu().numpy(), rtol=4e-3, atol=4e-3)
 
 
-def test_unsupported_shape_uses_library_gemms(cuda):
+SHAPES = [(8, 32, 2), (8, 32, 3), (32, 32, 3), (32, 64, 2), (16, 64, 3), (2, 32, 2), (30, 64, 3)]  # (dim_in, hidden, layers)
+
+
+def _mlp_g(dev, din, hid, layers, seed=0):
     from mi3d.network import MLP
-    m = MLP(8, 4, 32, 2).to(cuda)  # BASELINE config 1's head
-    x = torch.randn(100, 8, device=cuda)
-    assert not m.fused_ok(x)
-    assert m(x).shape == (100, 4)
+    torch.manual_seed(seed)
+    m = MLP(din, 4, hid, layers).to(dev)
+    with torch.no_grad():
+        for l in m.net:
+            l.bias.uniform_(-0.3, 0.3)
+    return m
+
+
+@pytest.mark.parametrize("din,hid,layers", SHAPES)
+@pytest.mark.parametrize("n", [33, 5000])
+def test_generic_shapes_fp32(cuda, din, hid, layers, n):
+    """Every shape the reference's MLP class can build around this field (network_tcnn.py:13-32,37-45; BASELINE config 1
+    is 8 -> 32 -> 4) on the matrix cores, forward + every gradient, against fp64 torch."""
+    from mi3d import mlp_ops
+    m = _mlp_g(cuda, din, hid, layers, seed=3)
+    x = torch.randn(n, din, device=cuda, requires_grad=True)
+    assert m.fused_ok(x)
+    g = torch.randn(n, 4, device=cuda)
+    g[::5] = 0
+    y = mlp_ops.fused_mlp(x, m.net, half_mode=False)
+    y.backward(g)
+    got = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    md = _mlp_g(cuda, din, hid, layers, seed=3).double()
+    xd = x.detach().double().requires_grad_()
+    yd = _torch_forward(md, xd)
+    yd.backward(g.double())
+    want = [yd.detach(), xd.grad] + [p.grad for p in md.parameters()]
+    names = ["y", "dx"] + [n_ for n_, _ in m.named_parameters()]
+    for nm, a, b in zip(names, got, want):
+        b = b.float()
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (nm, din, hid, layers)
+
+
+@pytest.mark.parametrize("din,hid,layers", SHAPES)
+def test_generic_shapes_fp16_mode_matches_autocast(cuda, din, hid, layers):
+    m = _mlp_g(cuda, din, hid, layers, seed=4)
+    n = 20000
+    x = (torch.randn(n, din, device=cuda) * 0.5).requires_grad_()
+    g = torch.randn(n, 4, device=cuda) * 64
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(x)
+    y.backward(g)
+    got = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    x.grad = None
+    m.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        yr = _torch_forward(m, x)
+    yr.backward(g.half())
+    want = [yr.detach().float(), x.grad.float()] + [p.grad.float() for p in m.parameters()]
+    names = ["y", "dx"] + [n_ for n_, _ in m.named_parameters()]
+    for nm, a, b in zip(names, got, want):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 8e-3 * scale, (nm, din, hid, layers)
+
+
+@pytest.mark.parametrize("din,hid,layers", [(32, 64, 3), (8, 32, 2), (16, 64, 2)])
+@pytest.mark.parametrize("half", [False, True])
+def test_plane_layouts_equal_row_layout(cuda, din, hid, layers, half):
+    """x / dx as level-major planes [din/2][rows][2] (fp32 and binary16 pairs) through the C ABI = the [n, din] rows."""
+    from mi3d import _lib as L, mlp_ops
+    m = _mlp_g(cuda, din, hid, layers, seed=5)
+    n, rows = 3000, 3333   # plane_rows > n: a prefix of wider planes
+    x = torch.randn(n, din, device=cuda) * 0.5
+    if half:
+        x = x.half().float()
+    g = torch.randn(n, 4, device=cuda)
+    ws = [None if t is None else t.detach().contiguous() for t in mlp_ops.layer_args(m.net)]
+    dims = (din, hid, 4)
+    mode = 1 if half else 0
+
+    def run(xt, x_rows, dx, dx_rows, ph):
+        out = torch.empty(n, 4, device=cuda)
+        grads = [None if t is None else torch.zeros_like(t) for t in ws]
+        L.call("mi3d_mlp_forward", L.ptr(xt), x_rows, ph, n, *[L.ptr(t) for t in ws], *dims, mode, L.ptr(out), L.stream())
+        L.call("mi3d_mlp_backward", L.ptr(xt), x_rows, ph, L.ptr(g), n, *[L.ptr(t) for t in ws], *dims, mode, L.ptr(dx),
+               dx_rows, *[L.ptr(t) for t in grads], L.stream())
+        return out, grads
+    dx_rows_t = torch.empty(n, din, device=cuda)
+    o0, g0 = run(x.contiguous(), 0, dx_rows_t, 0, 0)
+    planes = torch.zeros(din // 2, rows, 2, device=cuda)
+    planes[:, :n] = x.view(n, din // 2, 2).permute(1, 0, 2)
+    if half:
+        planes = planes.half()
+    dxp = torch.zeros(din // 2, rows, 2, device=cuda, dtype=planes.dtype)
+    o1, g1 = run(planes.contiguous(), rows, dxp, rows, int(half))
+    assert torch.equal(o0, o1)
+    dx1 = dxp[:, :n].permute(1, 0, 2).reshape(n, din).float()
+    want = dx_rows_t.half().float() if half else dx_rows_t
+    np.testing.assert_allclose(dx1.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=0)
+    assert float(dxp[:, n:].abs().max()) == 0.0   # rows past n are not touched
+    for a, b in zip(g0, g1):
+        if a is not None:   # float-atomic sums over the workgroups: equal up to summation order
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * float(a.abs().max()) + 1e-7)
+
+
+def test_uncovered_shape_raises_on_the_gpu(cuda):
+    """No eager / library-GEMM path on the GPU: a shape outside the kernels' coverage is an error."""
+    from mi3d import _lib as L
+    from mi3d.network import MLP
+    for m in (MLP(8, 4, 48, 2), MLP(64, 4, 64, 3), MLP(8, 3, 32, 2), MLP(8, 4, 32, 4), MLP(8, 4, 32, 2, bias=False)):
+        m = m.to(cuda)
+        x = torch.randn(10, m.dim_in, device=cuda)
+        assert not m.fused_ok(x)
+        with pytest.raises(L.Mi3dError):
+            m(x)

@@ -134,3 +134,38 @@ def test_config5_size_properties(cuda):
     lhs = float((out.detach().double() * g.double()).sum())
     rhs = float((feats.detach().double() * feats.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+
+
+def test_refine_train_step_draws_its_own_timestep(cuda):
+    """mi3d.refine.refine_train_step with t=None (nerf/utils.py:839-894): without a CLIP model every draw must land on
+    the SDS branch (the denoise + CLIP branch of sd.py:153 cannot run without one); with the CLIP stand-in, ref_rgb and
+    ref_text the t <= 400 draws take that branch and its loss value joins the step's loss."""
+    from mi3d import rays as R, refine, sd_standin as S
+    torch.manual_seed(0)
+    P, H = 4000, 64
+    d = torch.randn(P, 3, device=cuda)
+    points = (d / d.norm(dim=-1, keepdim=True) * 0.35).contiguous()
+    colour = torch.nn.Parameter(torch.rand(P, 3, device=cuda))
+    feat = torch.nn.Parameter(torch.randn(P, 16, device=cuda))
+    origin = colour.detach().clone()
+    unet = refine.UNet(num_input_channels=19).to(cuda).train()
+    opt = torch.optim.Adam([colour, feat] + list(unet.parameters()), lr=1e-3)
+    g = S.StableDiffusionStandIn(cuda, dtype=torch.float32, with_decoder=True,
+                                 unet_kw=dict(ch=(64, 64, 64, 64), ctx_dim=32, layers=1),
+                                 vae_kw=dict(ch=(32, 32, 32, 32), layers=1), decoder_kw=dict(ch=(32, 32, 32, 32), layers=1))
+    text_z = torch.randn(2, 77, 32, device=cuda)
+    w2c = torch.linalg.inv(R.orbit_pose(1.25, 80.0, 30.0, device=cuda)[0])
+    focal = 1.0 / (2 * np.tan(np.radians(20) / 2))
+    args = (unet, {"colour": colour, "feat": feat}, opt, g, text_z, points, w2c, focal, H, H, 2.0 / H * 2.0, 8, origin)
+    for _ in range(12):   # (0.2, 0.6) step range: about half of unrestricted draws would be <= 400
+        loss = refine.refine_train_step(*args)
+        assert torch.isfinite(loss)
+    clip = S.CLIPStandIn(width=64, layers=2, heads=2, embed=32, text_width=32, text_layers=2, text_heads=2).to(cuda)
+    for p in clip.parameters():
+        p.requires_grad_(False)
+    ref_rgb = torch.rand(1, 3, 512, 512, device=cuda)
+    base = float(refine.refine_train_step(*args, t=500, clip_model=clip, ref_rgb=ref_rgb, ref_text="a toy"))
+    with_clip = float(refine.refine_train_step(*args, t=300, clip_model=clip, ref_rgb=ref_rgb, ref_text="a toy"))
+    assert np.isfinite(base) and np.isfinite(with_clip)
+    for _ in range(6):
+        assert torch.isfinite(refine.refine_train_step(*args, clip_model=clip, ref_rgb=ref_rgb, ref_text="a toy"))

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--workload", default="c2_dense")
     ap.add_argument("--dev", default="", help="development build tunables, e.g. 3=2048 (emit fine waves)")
+    ap.add_argument("--scale", type=float, default=4.0,
+                    help="GradScaler loss scale (bench.py settles at 4.0 on this workload: profile at the SAME state)")
     a = ap.parse_args()
     if a.dev:
         _dev_tunables(a.dev)
@@ -39,7 +41,7 @@ def main():
     wl = bench.WORKLOADS[a.workload]
     dev = torch.device("cuda:0")
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
-    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"], init_scale=0.25)
+    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"], init_scale=a.scale)
     ro, rd, ds = R.view_rays(wl["H"], wl["W"], device=dev)
     for i in range(a.iters):
         torch.cuda.synchronize()

@@ -118,13 +118,18 @@ def main():
             L.call("mi3d_mlp_backward", L.ptr(feats), P * n, int(feats.dtype == torch.float16), L.ptr(dh), rows,
                    *[L.ptr(t) for t in ws], 32, 64, 4, 1,
                    L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream())
-        for v in (0, 1, 2):   # 0: two tiles per wave (staged), 1: one tile per wave, 2: one tile, 2 waves/SIMD (spills)
+        for v in (0, 3):   # 0: round 3's kernels (two waves per SIMD, VGPR-form MFMA, transposes); 3: round 2's
             tune(6, v)
-            for w in ((2, 4) if v == 2 else (1, 2)):
+            res[f"mlp_fwd_variant{v}_ms"] = timeit(fwd, a.iters)
+            for w in (1, 2):
                 tune(T_MLP_WGS, w)
                 res[f"mlp_bwd_variant{v}_wgs{w}_ms"] = timeit(bwd, a.iters)
+            tune(T_MLP_WGS, -1)
         tune(6, -1)
-        tune(T_MLP_WGS, -1)
+        for w in (2, 3, 4, 5, 6):
+            tune(11, w)   # MI3D_T_MLP_FWD_WGS_PER_CU
+            res[f"mlp_fwd_wgs{w}_ms"] = timeit(fwd, a.iters)
+        tune(11, -1)
         res["mlp_bwd_ms"] = timeit(bwd, a.iters)
         res["mlp_bwd_point0_only_ms"] = timeit(lambda: bwd(n), a.iters)
         res["mlp_bwd_TFLOPs"] = P * n * 25600.0 / res["mlp_bwd_ms"] / 1e9
@@ -134,6 +139,18 @@ def main():
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
         res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240), a.iters)
+        del g
+    if "scatter_levels" in what:  # the 13-point scatter per role and per level (dev level mask), dense random gradients
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        masks = {"all": 0xFFFF, "fine_8_15": 0xFF00, "coarse_0_7": 0x00FF}
+        masks.update({f"level{l}": 1 << l for l in range(16)})
+        out = {}
+        for name, mk in masks.items():
+            tune(5, mk)
+            out[name] = timeit(lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024,
+                                                                12196240), 2)
+        tune(5, -1)
+        res["scatter13_dense_ms_by_level_mask"] = out
         del g
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
