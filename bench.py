@@ -248,6 +248,54 @@ def log(msg):
     sys.stderr.flush()
 
 
+def product_c1_gpu(dev):
+    """BASELINE config 1 on the PRODUCT: the same 64x64 x 64-sample render through mi3d's NeRFRenderer.run (the
+    reference's PyTorch sampler path restated) with the L=4 hash grid and the 8 -> 32 -> 4 MLP on the HIP kernels, fp32,
+    forward only and forward + backward; HIP events, 3 warm-up + 10 timed calls, median."""
+    import statistics
+    import numpy as np
+    import torch
+    from mi3d import network, rays as R, sds_step
+    opt = sds_step.make_opt(cuda_ray=False, lambda_smooth=0.0, fp16=False)
+    torch.manual_seed(0)
+    net = network.NeRFNetwork(opt, num_layers=2, hidden_dim=32, n_levels=4, per_level_scale=float(128 ** (1 / 3))).to(dev)
+    net.train()
+    ro, rd, _ = R.view_rays(64, 64, device=dev)
+    N, steps = ro.shape[1], 64
+    bg = torch.ones(N, 3, device=dev)
+
+    def forward():
+        return net.run(ro, rd, num_steps=steps, upsample_steps=0, bg_color=bg, perturb=True, ambient_ratio=1.0,
+                       shading="albedo")
+
+    def fwd_only():
+        with torch.no_grad():
+            forward()
+
+    def fwd_bwd():
+        net.zero_grad()
+        out = forward()
+        ((out["image"] ** 2).mean() + out["loss_orient"]).backward()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
+    tf, tb = timed(fwd_only), timed(fwd_bwd)
+    return {"forward_ms": tf, "forward_backward_ms": tb, "forward_rays_per_s": N / tf * 1e3,
+            "forward_backward_rays_per_s": N / tb * 1e3, "forward_backward_samples_per_s": N * steps / tb * 1e3,
+            "what": "the same config-1 render (4096 rays x 64 samples, 7 field evaluations per sample) through "
+                    "mi3d.renderer.NeRFRenderer.run on this GPU: L=4 hash grid + 8->32->4 MLP on the HIP kernels, fp32"}
+
+
 def _cpu_leg(kind, workload, hard_limit_s):
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload",
@@ -296,6 +344,9 @@ def main():
     ap.add_argument("--no-reference-shaped", action="store_true")
     ap.add_argument("--init-scale", type=float, default=65536.0,
                     help="GradScaler initial loss scale (the reference's: torch's default, nerf/utils.py:309)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (under torch.distributed.run): the "
+                         "gradient all-reduce, the state broadcast and the occupancy broadcast then really execute")
     ap.add_argument("--cpu-baseline-only", default=None, choices=["c1", "reference", "port"], help=argparse.SUPPRESS)
     ap.add_argument("--refresh-every", type=int, default=16,
                     help="update_extra_state interval inside the timed loop (nerf/utils.py:970-972; 0 = never)")
@@ -323,8 +374,12 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -421,18 +476,18 @@ def main():
         grid_ops.PROFILE = {"scatter": [], "encode": []}
         torch.cuda.reset_peak_memory_stats(dev)
         scale0 = scaler.get_scale() if not render_only else None
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         prof, grid_ops.PROFILE = grid_ops.PROFILE, None
-        if world > 1:
+        if dist.is_initialized():
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -589,12 +644,22 @@ def main():
             if line["reference_shaped_baseline"].get("value"):
                 line["speedup_vs_reference_shaped"] = line["value"] / line["reference_shaped_baseline"]["value"]
         if not args.no_cpu_baseline:
-            log("cpu baseline (child process, hard limit 150 s per leg)")
+            log("cpu baseline (child processes, hard limit 150 s per leg)")
             line["cpu_baseline"] = cpu_baseline(args.workload)
+            try:
+                line["cpu_baseline"]["product_c1_gpu"] = product_c1_gpu(dev)
+                fb = line["cpu_baseline"].get("forward_backward_ms")
+                if fb:
+                    line["cpu_baseline"]["product_c1_gpu"]["speedup_vs_cpu_forward_backward"] = \
+                        fb / line["cpu_baseline"]["product_c1_gpu"]["forward_backward_ms"]
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"]["product_c1_gpu"] = {"error": repr(e)}
         log("done")
     if rank == 0:
+        if dist.is_initialized():
+            line["collectives"] = dict(dp.STATS, backend=dist.get_backend(), world_size=world)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
 
-struct EncodeSeg { uint32_t level, tile0, tile1; };
+struct EncodeSeg { uint32_t level, tile0, tile1, wgs; };  // wgs: workgroups of the XCD that walk this segment
 struct EncodePlan {
     uint32_t n_seg[kXcds];
     EncodeSeg seg[kXcds][kMaxSegs];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
                                                                        int out_half) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
+    const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds;
     const size_t rows_total = (size_t)n * ps.P;
     for (uint32_t sg = 0; sg < plan.n_seg[xcd]; ++sg) {
         const EncodeSeg seg = plan.seg[xcd][sg];
@@ -226,7 +226,11 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
         const size_t plane0 = (size_t)l * rows_total;
-        for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += wgs_per_xcd * kWaves) {
+        // a coarse level is latency-bound and wants every workgroup the launch has (6 per CU); a fine level thrashes the
+        // L1 beyond 3 per CU - the surplus workgroups skip its segments (and, the segments being ordered coarse to fine,
+        // retire once the coarse ones are done)
+        if (wg_in_xcd >= seg.wgs) continue;
+        for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += seg.wgs * kWaves) {
             const uint32_t s = tile * kTile + lane;
             if (s >= n) continue;
             float base[2][3];
@@ -258,17 +262,22 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
 // level two consecutive samples of a ray are apart: the measured per-level times above, tabulated against x (C2: step
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
 inline double encode_level_cost(double x) {
+    // round 3 (profiles/kbench_r03_encode_wgs.json): ms per level at C2 with 6 workgroups per CU up to x = 0.26 and 3 beyond
     static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
-    static const double cs[] = {1.17, 1.18, 1.22, 1.28, 1.42, 1.74, 2.36, 2.99, 3.35, 3.46, 3.49, 3.51};
+    static const double cs[] = {0.84, 0.85, 0.91, 1.00, 1.22, 1.53, 1.90, 2.60, 2.95, 3.08, 3.12, 3.15};
     constexpr int N = sizeof(xs) / sizeof(xs[0]);
     if (x <= xs[0]) return cs[0];
     for (int i = 1; i < N; ++i)
         if (x < xs[i]) return cs[i - 1] + (cs[i] - cs[i - 1]) * (x - xs[i - 1]) / (xs[i] - xs[i - 1]);
     return cs[N - 1];
 }
+// workgroups per CU a level is walked with: measured per level (same file) - 0.84 ms at 6 against 1.06 at 3 for the
+// coarse levels, 1.53 at 3 against 1.67 at 6 where a wave's lanes sit in different lines (x = cells per marching step)
+inline uint32_t encode_level_wgs_per_cu(double x, uint32_t coarse, uint32_t fine) { return x < 0.30 ? coarse : fine; }
 
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
-inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level) {
+inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level,
+                                   uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
@@ -288,7 +297,9 @@ inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float s
             uint32_t take = (x + 1 == kXcds) ? n_tiles - t0 : (uint32_t)ceil(room / cost[l] * (double)n_tiles - 1e-9);
             if (take > n_tiles - t0) take = n_tiles - t0;
             if (take > 0 && plan.n_seg[x] < (uint32_t)kMaxSegs) {
-                plan.seg[x][plan.n_seg[x]++] = EncodeSeg{l, t0, t0 + take};
+                const uint32_t wgs = encode_level_wgs_per_cu((double)step01 * (double)T.level[l].scale,
+                                                             wgs_coarse_per_xcd, wgs_fine_per_xcd);
+                plan.seg[x][plan.n_seg[x]++] = EncodeSeg{l, t0, t0 + take, wgs};
                 filled += cost[l] * (double)take / (double)n_tiles;
                 t0 += take;
             }
@@ -634,6 +645,10 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
             run = run < 1.0 ? 1.0 : run;
             per = per / run * 2.0;
         }
+        // merged (coarse) levels emit one record per distinct entry a tile touched: measured 3-6 % of the per-contribution
+        // count (tools/scatter_fill.py, profiles/scatter_fill_r02.json) - their regions get a fifth of it (round 2 sized
+        // them for every contribution: 52 of the arena's 92 GiB at C2).  A full region is not an error (float atomics).
+        if (merged) per *= 0.2;
         p.level_cap[l] = (uint32_t)per + 64u;
         // fine fp32 levels whose x-neighbour entries are derivable from each other: one 16-byte record per corner pair
         const bool row = !merged && L.size <= (1u << kRowEntryBits) &&
@@ -723,6 +738,13 @@ __device__ __forceinline__ unsigned long long fixed_point(float x) {
 // handful of bins to reduce them in.  This merges across lanes, runs AND stencil points.)  A contribution that finds no
 // slot within kMergeProbes goes out as a record of its own.
 constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFFFu;
+// Fine levels: the x-pair records of kChunkPts stencil points of a tile (64 lanes x 4 pairs each) are SORTED BY BIN in the
+// wave's LDS before they leave, so that what goes to a region is a contiguous run of records (consecutive lanes store
+// consecutive 16-byte slots) instead of one scattered 16-byte store per lane.  The staging area is the memory the coarse
+// role uses for its gather table (a wave has one role): 2 * kMergeSlots 64-bit words = 512 records.
+constexpr uint32_t kChunkPts = 2, kStageRecs = kWave * 4 * kChunkPts;
+static_assert(kStageRecs * 16 == 2 * kMergeSlots * 8, "the staging area is the gather table's sums");
+static_assert(3 * 64 <= kMergeSlots, "histogram, cursors and region deltas live in the gather table's keys");
 __host__ __device__ inline uint32_t emit_wave_words(uint32_t n_bins) {  // 32-bit words of LDS per emitting wave (even)
     return 4u * kMergeSlots + kMergeSlots + ((n_bins + 1u) & ~1u);
 }
@@ -853,33 +875,189 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
             uint32_t bx = 0, by = 0, bz = 0;  // the cell of the current group's base position
             float acc0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             bool acc_any = false;
-            auto gather = [&](uint32_t e, float g0, float g1) {  // (e, g0, g1) into the wave's gather table (kMergeSlots)
-                uint32_t slot = (e * 2654435761u) >> (32 - 9);
+            // The 8 corners of a cell into the wave's gather table (kMergeSlots).  All eight first probes are issued
+            // before any of their results is looked at: an LDS compare-and-swap returns after ~120 cycles, and eight
+            // dependent probe loops in a row (round 2) made the coarse role a chain of LDS latencies - 36 of the 61 ms of
+            // a dense 13-point emit (rocprofv3 per level, profiles/kernel_trace_r03_scatter_levels.csv).  A probe that
+            // finds its slot taken by another entry (rare at 512 slots for a few hundred entries) walks on alone.
+            auto gather8 = [&](uint32_t ex, uint32_t ey, uint32_t ez, const float (&g0)[8], const float (&g1)[8]) __attribute__((always_inline)) {
                 static_assert(kMergeSlots == 512, "the slot hash keeps 9 bits");
-                bool placed = false;
-                for (uint32_t tries = 0; tries < kMergeProbes; ++tries) {
-                    const uint32_t old = atomicCAS(&keys[slot], kMergeEmpty, e);
-                    if (old == kMergeEmpty || old == e) { placed = true; break; }
-                    slot = (slot + 1u) & (kMergeSlots - 1u);
-                }
-                if (placed) {
-                    atomicAdd(&sums[2 * slot], fixed_point(g0 * merge_scale));
-                    atomicAdd(&sums[2 * slot + 1], fixed_point(g1 * merge_scale));
-                } else {
-                    emit_record(plan, L, l, gw, e, g0, g1, fill, arena, grad_table, lmax);
+#pragma unroll
+                for (uint32_t half = 0; half < 2; ++half) {  // two batches of four probes in flight (registers)
+                    uint32_t e[4], slot[4], old[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t k = 4 * half + j;
+                        e[j] = grid_entry(L, ex + (k & 1u), ey + ((k >> 1) & 1u), ez + (k >> 2));
+                        slot[j] = (e[j] * 2654435761u) >> (32 - 9);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t k = 4 * half + j;
+                        old[j] = (g0[k] != 0.f || g1[k] != 0.f) ? atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]) : e[j];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t k = 4 * half + j;
+                        if (!(g0[k] != 0.f || g1[k] != 0.f)) continue;
+                        bool placed = old[j] == kMergeEmpty || old[j] == e[j];
+                        for (uint32_t tries = 1; !placed && tries < kMergeProbes; ++tries) {
+                            slot[j] = (slot[j] + 1u) & (kMergeSlots - 1u);
+                            const uint32_t o = atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]);
+                            placed = o == kMergeEmpty || o == e[j];
+                        }
+                        if (placed) {
+                            atomicAdd(&sums[2 * slot[j]], fixed_point(g0[k] * merge_scale));
+                            atomicAdd(&sums[2 * slot[j] + 1], fixed_point(g1[k] * merge_scale));
+                        } else {
+                            emit_record(plan, L, l, gw, e[j], g0[k], g1[k], fill, arena, grad_table, lmax);
+                        }
+                    }
                 }
             };
-            auto flush_group = [&]() {
+            auto flush_group = [&]() __attribute__((always_inline)) {
                 if (acc_any) {
+                    gather8(bx, by, bz, acc0, acc1);
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) {
-                        if (acc0[k] != 0.f || acc1[k] != 0.f)
-                            gather(grid_entry(L, bx + (k & 1u), by + ((k >> 1) & 1u), bz + (k >> 2)), acc0[k], acc1[k]);
-                        acc0[k] = 0.f; acc1[k] = 0.f;
-                    }
+                    for (uint32_t k = 0; k < 8; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
                 }
                 acc_any = false;
             };
+            if (!merge && ((plan.row_mask >> l) & 1u)) {
+                // ---- fine level: one 16-byte record per x-corner pair {e0 | t << 19, a, b, fx}, sorted by bin in LDS
+                // kChunkPts stencil points at a time.  What round 2's counters and this round's per-level traces say
+                // about the scattered version (one 16-byte store per lane and record): 123 G records/s per level
+                // whatever the instruction stream - the rate at which the L2s take partial-line writes - and 1536
+                // emitting waves at most, because every open line of every (wave, bin) region had to stay in the L2s
+                // until its 8th record arrived.  Sorted runs leave as whole lines.
+                uint4 *stage = reinterpret_cast<uint4 *>(sums);
+                uint32_t *hist = keys, *cursor = keys + 64, *gdelta = keys + 128;
+                const uint32_t mask = L.size - 1u;
+                auto to_table = [&](uint32_t e, float va, float vb) __attribute__((always_inline)) {  // straight to the table (float atomics)
+                    float *dst = grad_table + ((size_t)L.offset + e) * 2;
+                    unsafeAtomicAdd(dst, va); unsafeAtomicAdd(dst + 1, vb);
+                };
+                auto put_single = [&](uint32_t e, float va, float vb) __attribute__((always_inline)) {  // a record of its own, appended directly
+                    const uint32_t bin = e >> kBinShift;
+                    const uint32_t slot = atomicAdd(&fill_l[bin], 1u);
+                    if (slot < cap) region0[__umul24(bin, cap) + slot] = RowRecord{e, va, vb, 0.f};
+                    else to_table(e, va, vb);
+                };
+                // the four (y, z) corner pairs of a cell: e0 = entry of the x corner, e1 = of the x + 1 corner
+                auto pair_entries = [&](uint32_t cx, uint32_t cy, uint32_t cz, uint32_t j, uint32_t &e0, uint32_t &e1) __attribute__((always_inline)) {
+                    if (L.hashed) {  // e(x + 1) = e(x) ^ flip, flip = the bits a +1 carry changes in cx (x enters with prime 1)
+                        e0 = (cx ^ ((cy + (j & 1u)) * kPrimeY) ^ ((cz + (j >> 1)) * kPrimeZ)) & mask;
+                        e1 = e0 ^ ((cx ^ (cx + 1u)) & mask);
+                    } else {
+                        e0 = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
+                        e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
+                    }
+                };
+                // a pair record needs both entries in one bin AND derivable from each other: hashed e1 = e0 ^ flip by
+                // construction, dense e1 = e0 + 1 (not where grid_entry wraps the +1 corner to entry 0)
+                auto pairable = [&](uint32_t e0, uint32_t e1) __attribute__((always_inline)) {
+                    return (e0 >> kBinShift) == (e1 >> kBinShift) && (L.hashed || e1 == e0 + 1u);
+                };
+                hist[lane] = 0u;
+                for (uint32_t p0 = 0; p0 < ps.P; p0 += kChunkPts) {
+                    uint32_t ccx[kChunkPts], ccy[kChunkPts], ccz[kChunkPts];
+                    float cfx[kChunkPts], cfy[kChunkPts], cfz[kChunkPts], cd0[kChunkPts], cd1[kChunkPts];
+                    bool cok[kChunkPts];
+                    // pass 1: cells, and how many records each bin gets
+#pragma unroll
+                    for (uint32_t c = 0; c < kChunkPts; ++c) {
+                        const uint32_t p = p0 + c;  // uniform
+                        uint32_t r0 = raw0[0], r1 = raw1[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[k] : r1; }
+                        const float2 d = planes_half
+                            ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
+                                          (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
+                            : make_float2(__uint_as_float(r0), __uint_as_float(r1));
+                        const bool has = valid && p < ps.P && (d.x != 0.f || d.y != 0.f);
+                        const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
+                        float q[3];
+                        point_of(ps, base, p < ps.P ? p : 0u, q);
+                        grid_cell(q[0], L.scale, ccx[c], cfx[c]);
+                        grid_cell(q[1], L.scale, ccy[c], cfy[c]);
+                        grid_cell(q[2], L.scale, ccz[c], cfz[c]);
+                        cd0[c] = d.x; cd1[c] = d.y;
+                        cok[c] = has && finite;
+                        if (cok[c]) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
+                        if (has) {
+                            const float gx = 1.0f - cfx[c], gy = 1.0f - cfy[c], gz = 1.0f - cfz[c];
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                uint32_t e0, e1;
+                                pair_entries(ccx[c], ccy[c], ccz[c], j, e0, e1);
+                                if (finite && pairable(e0, e1)) {
+                                    __hip_atomic_fetch_add(&hist[e0 >> kBinShift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                } else {
+                                    // rare: a pair that straddles two bins leaves as two singles right away; a non-finite
+                                    // gradient goes to the table with float atomics - on exactly the entries the
+                                    // reference's atomicAdd would have put the inf / NaN
+                                    const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
+                                    const float a = w * d.x, b = w * d.y;
+                                    if (finite) { put_single(e0, gx * a, gx * b); put_single(e1, cfx[c] * a, cfx[c] * b); }
+                                    else { to_table(e0, gx * a, gx * b); to_table(e1, cfx[c] * a, cfx[c] * b); }
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // lane = bin: where the bin's run starts in the staging area and in its region
+                    const uint32_t cnt = hist[lane];
+                    uint32_t incl = cnt;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t up = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += up;
+                    }
+                    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                    const uint32_t excl = incl - cnt, g = fill_l[lane];
+                    cursor[lane] = excl;
+                    gdelta[lane] = g - excl;
+                    if (cnt) fill_l[lane] = g + cnt;
+                    hist[lane] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    // pass 2: the records, each to its place
+#pragma unroll
+                    for (uint32_t c = 0; c < kChunkPts; ++c) {
+                        if (cok[c]) {
+                            const float gy = 1.0f - cfy[c], gz = 1.0f - cfz[c];
+                            const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~ccx[c]) + 1u : 0u;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                uint32_t e0, e1;
+                                pair_entries(ccx[c], ccy[c], ccz[c], j, e0, e1);
+                                if (pairable(e0, e1)) {
+                                    const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
+                                    const uint32_t pos = atomicAdd(&cursor[e0 >> kBinShift], 1u);
+                                    stage[pos] = make_uint4(e0 | (t << kRowEntryBits), __float_as_uint(w * cd0[c]),
+                                                            __float_as_uint(w * cd1[c]), __float_as_uint(cfx[c]));
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // the sorted records leave: consecutive lanes, consecutive slots of a region
+                    for (uint32_t i = lane; i < total; i += kWave) {
+                        const uint4 rec = stage[i];
+                        const uint32_t e0 = rec.x & ((1u << kRowEntryBits) - 1u), bin = e0 >> kBinShift;
+                        const uint32_t slot = i + gdelta[bin];
+                        if (slot < cap) {
+                            reinterpret_cast<uint4 *>(region0)[__umul24(bin, cap) + slot] = rec;
+                        } else {  // region full: straight to the table
+                            const float a = __uint_as_float(rec.y), b = __uint_as_float(rec.z), fx = __uint_as_float(rec.w);
+                            const uint32_t tt = rec.x >> kRowEntryBits;
+                            const uint32_t e1 = L.hashed ? (e0 ^ (((1u << tt) - 1u) & mask)) : e0 + 1u;
+                            to_table(e0, (1.0f - fx) * a, (1.0f - fx) * b);
+                            if (fx != 0.f) to_table(e1, fx * a, fx * b);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else
             for (uint32_t p = 0; p < ps.P; ++p) {
                 if (merge && (p == 0u || p == ps.P0)) {  // a new group of stencil points: around x, then around x2
                     flush_group();
@@ -919,59 +1097,6 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
                 const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
                 const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                if (!merge && ((plan.row_mask >> l) & 1u)) {  // fine level, one 16-byte record per x-corner pair
-                    // Written for few instructions: two integer multiplies per point instead of sixteen (the +1 neighbours of a hash term differ by
-                    // the prime), the x + 1 entry derived from the x entry, the level's maximum taken from the gradient
-                    // pair (every contribution is a weight <= 1 times it), a 32-bit index into this wave's regions.
-                    if (has) {
-                        // a non-finite gradient pair: its contributions take the float-atomic path below (every put() of
-                        // this lane is refused), exactly the entries the reference's atomicAdd would have poisoned
-                        const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
-                        if (finite) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
-                        const float wyz[4] = {gy * gz, fy * gz, gy * fz, fy * fz};
-                        auto put = [&](uint32_t e, uint32_t tt, float va, float vb, float vfx) {
-                            if (!finite) return false;
-                            const uint32_t bin = e >> kBinShift;
-                            const uint32_t slot = atomicAdd(&fill_l[bin], 1u);  // wave-private LDS counter
-                            if (slot < cap) {
-                                region0[__umul24(bin, cap) + slot] = RowRecord{e | (tt << kRowEntryBits), va, vb, vfx};
-                                return true;
-                            }
-                            return false;
-                        };
-                        auto to_table = [&](uint32_t e, float va, float vb) {  // region full: straight to the table
-                            float *dst = grad_table + ((size_t)L.offset + e) * 2;
-                            unsafeAtomicAdd(dst, va); unsafeAtomicAdd(dst + 1, vb);
-                        };
-                        // hashed (2^k entries): e(x + 1) = e(x) ^ flip, flip = the bits a +1 carry changes in cx, and
-                        // t = their count goes into the record so that the reduce can do the same; dense: t = 0, "+1"
-                        const uint32_t mask = L.size - 1u;
-                        const uint32_t flip = (cx ^ (cx + 1u)) & mask;
-                        const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~cx) + 1u : 0u;
-                        const uint32_t hy0 = cy * kPrimeY, hy1 = hy0 + kPrimeY, hz0 = cz * kPrimeZ, hz1 = hz0 + kPrimeZ;
-#pragma unroll
-                        for (uint32_t j = 0; j < 4; ++j) {
-                            uint32_t e0, e1;
-                            if (L.hashed) {
-                                e0 = (cx ^ ((j & 1u) ? hy1 : hy0) ^ ((j >> 1) ? hz1 : hz0)) & mask;
-                                e1 = e0 ^ flip;
-                            } else {
-                                e0 = grid_entry(L, cx, cy + (j & 1u), cz + (j >> 1));
-                                e1 = grid_entry(L, cx + 1u, cy + (j & 1u), cz + (j >> 1));
-                            }
-                            const float a = wyz[j] * d.x, b = wyz[j] * d.y;
-                            // a pair record needs both entries in one bin AND derivable from each other: hashed e1 = e0 ^ flip
-                            // by construction, dense e1 = e0 + 1 (not where grid_entry wraps the +1 corner to entry 0)
-                            if ((e0 >> kBinShift) == (e1 >> kBinShift) && (L.hashed || e1 == e0 + 1u)) {
-                                if (!put(e0, t, a, b, fx)) { to_table(e0, gx * a, gx * b); to_table(e1, fx * a, fx * b); }
-                            } else {  // the pair straddles two bins: two singles (fx = 0: only the header's entry receives (a, b))
-                                if (!put(e0, 0u, gx * a, gx * b, 0.f)) to_table(e0, gx * a, gx * b);
-                                if (!put(e1, 0u, fx * a, fx * b, 0.f)) to_table(e1, fx * a, fx * b);
-                            }
-                        }
-                    }
-                    continue;
-                }
                 if (!merge) {  // fine level without the pair structure: every point emits its 8 corners
                     // (appending the two 12-byte records of an x-pair together - one counter update, 24 contiguous
                     // bytes - was measured: 106 -> 114 ms per 141 M evaluations; the store path is paid per lane-store)
@@ -986,11 +1111,12 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 }
                 if (dead) {  // a tile with a non-finite gradient: plain float atomics, entry by entry
                     if (has) {
-#pragma unroll
-                        for (uint32_t k = 0; k < 8; ++k) {
+#pragma unroll 1
+                        for (uint32_t k = 0; k < 8; ++k) {  // (rare path: kept rolled, it must not cost the kernel registers)
+                            const float wkk = ((k & 1u) ? fx : gx) * ((k & 2u) ? fy : gy) * ((k & 4u) ? fz : gz);
                             float *dst = grad_table + ((size_t)L.offset + grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))) * 2;
-                            unsafeAtomicAdd(dst, wk[k] * d.x);
-                            unsafeAtomicAdd(dst + 1, wk[k] * d.y);
+                            unsafeAtomicAdd(dst, wkk * d.x);
+                            unsafeAtomicAdd(dst + 1, wkk * d.y);
                         }
                     }
                     continue;
@@ -1003,9 +1129,10 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
 #pragma unroll
                     for (uint32_t k = 0; k < 8; ++k) { acc0[k] += wk[k] * d.x; acc1[k] += wk[k] * d.y; }
                 } else if (has) {
+                    float v0[8], v1[8];
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k)
-                        gather(grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2)), wk[k] * d.x, wk[k] * d.y);
+                    for (uint32_t k = 0; k < 8; ++k) { v0[k] = wk[k] * d.x; v1[k] = wk[k] * d.y; }
+                    gather8(cx, cy, cz, v0, v1);
                 }
             }
             if (merge) flush_group();
@@ -1237,11 +1364,14 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const uint32_t tiles = (n + kTile - 1) / kTile;
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     const int variant = MI3D_TUNE(MI3D_T_ENCODE_VARIANT, 3);
-    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1));
-    uint32_t per_xcd = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
-    const uint32_t per_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
-    const uint32_t cap = 32 * per_cu;                  // persistent beyond that many workgroups per CU
-    per_xcd = per_xcd < cap ? per_xcd : cap;
+    uint32_t need = (tiles + kWaves - 1) / kWaves;  // workgroups one XCD needs to give every tile its own wave
+    const uint32_t fine_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_WGS_PER_CU, 3);
+    const uint32_t coarse_cu = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_COARSE_WGS_PER_CU, 6);
+    const uint32_t wgs_fine = need < 32 * fine_cu ? need : 32 * fine_cu;        // 32 CUs per XCD; persistent beyond
+    uint32_t wgs_coarse = need < 32 * coarse_cu ? need : 32 * coarse_cu;
+    if (wgs_coarse < wgs_fine) wgs_coarse = wgs_fine;
+    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1), wgs_coarse, wgs_fine);
+    const uint32_t per_xcd = wgs_coarse;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     const float2 *tab = reinterpret_cast<const float2 *>(params);
     float *out = reinterpret_cast<float *>(out_planes);
@@ -1367,11 +1497,11 @@ int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    const EncodePlan plan = make_encode_plan(T, (n + kTile - 1) / kTile, step01, -1);
+    const EncodePlan plan = make_encode_plan(T, (n + kTile - 1) / kTile, step01, -1, 32 * 6, 32 * 3);
     for (uint32_t x = 0; x < kXcds; ++x) {
         n_segments[x] = plan.n_seg[x];
         for (uint32_t i = 0; i < (uint32_t)kMaxSegs; ++i) {
-            const EncodeSeg sg = i < plan.n_seg[x] ? plan.seg[x][i] : EncodeSeg{0u, 0u, 0u};
+            const EncodeSeg sg = i < plan.n_seg[x] ? plan.seg[x][i] : EncodeSeg{0u, 0u, 0u, 0u};
             segments[(x * kMaxSegs + i) * 3 + 0] = sg.level;
             segments[(x * kMaxSegs + i) * 3 + 1] = sg.tile0;
             segments[(x * kMaxSegs + i) * 3 + 2] = sg.tile1;

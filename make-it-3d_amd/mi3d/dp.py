@@ -10,6 +10,15 @@ gradients on every rank.  Works with any torch.distributed backend (tests run it
 import torch
 import torch.distributed as dist
 
+# how many collectives this process issued (bench.py reports them; tests/test_rccl_gpu.py checks the RCCL path really ran)
+STATS = {"all_reduce": 0, "broadcast": 0}
+
+
+def _active(group=None):
+    """Collectives run whenever a process group exists - also at world size 1 (one rank's all-reduce is a copy onto
+    itself), so that a single-GPU launch under torch.distributed.run exercises exactly the calls an 8-GPU run makes."""
+    return dist.is_available() and dist.is_initialized()
+
 
 class FlatGradBucket:
     def __init__(self, params, process_group=None):
@@ -51,31 +60,33 @@ class FlatGradBucket:
     def all_reduce_mean(self):
         """Average the bucket over the ranks (no-op without an initialised process group)."""
         self._check_views()
-        if not (dist.is_available() and dist.is_initialized()):
+        if not _active(self.group):
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
-            return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(world)
+        STATS["all_reduce"] += 1
+        if world > 1:
+            self.flat.div_(world)
 
 
 def broadcast_module_state(module, src=0, process_group=None):
     """Same initial weights, buffers (density grid / bitfield) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    if not _active(process_group):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src=src, group=process_group)
+            STATS["broadcast"] += 1
 
 
 def sync_occupancy(model, src=0, process_group=None):
     """After `update_extra_state` on rank `src` (it draws torch.rand jitter): ship the 262 144-byte bitfield
     and the mean density to the other ranks every 16 steps."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    if not _active(process_group):
         return
     dist.broadcast(model.density_bitfield, src=src, group=process_group)
     dist.broadcast(model.density_grid, src=src, group=process_group)
     md = torch.tensor([float(model.mean_density)], device=model.density_bitfield.device)
     dist.broadcast(md, src=src, group=process_group)
+    STATS["broadcast"] += 3
     model.mean_density = float(md.item())

@@ -27,7 +27,7 @@ from . import mlp_ops
 # the samples are processed in slices that fit (mi3d_grid_scatter_binned halves the slice until its plan fits the
 # workspace it is handed).  It is a plain torch allocation made per call: the caching allocator hands the same block
 # back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
-WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "32")) * (1 << 30))
+WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56")) * (1 << 30))
 
 
 def scatter_workspace(device, needed, cap=None):

@@ -90,6 +90,8 @@ def main():
             tune(T_ENCODE_WGS, w)
             res[f"encode_wgs{w}_ms"] = timeit(encode, a.iters)
         tune(T_ENCODE_WGS, -1)
+    if "encode1" in what:  # the product configuration of the gather, once
+        res["encode_ms"] = timeit(encode, 5)
     if "levels" in what:
         for v in (3,):
             tune(T_ENCODE_VARIANT, v)
@@ -101,6 +103,18 @@ def main():
         tune(T_ENCODE_ONLY_LEVEL, -1)
         tune(T_ENCODE_VARIANT, -1)
         encode()
+    if "levels_wgs" in what:  # do the coarse levels want more waves per SIMD than the fine ones?
+        tune(T_ENCODE_VARIANT, 3)
+        out = {}
+        for w in (2, 3, 4, 5, 6, 8):
+            tune(T_ENCODE_WGS, w)
+            for l in (0, 2, 4, 5, 6, 7, 8, 9, 11, 13, 15):
+                tune(T_ENCODE_ONLY_LEVEL, l)
+                out[f"wgs{w}_level{l}"] = timeit(encode, 2)
+        tune(T_ENCODE_ONLY_LEVEL, -1)
+        tune(T_ENCODE_WGS, -1)
+        tune(T_ENCODE_VARIANT, -1)
+        res["encode_level_ms_by_wgs_per_cu"] = out
     if "mlp" in what:
         net = model.sigma_net.net
         ws = [t.detach().contiguous() for l in net for t in (l.weight, l.bias)]
