@@ -180,8 +180,9 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
 /* The same scatter without global atomics: every corner contribution (on the coarse levels: what a wave's 64 samples
  * x P points contribute to one entry, summed in LDS first; on the fine levels: the two x-neighbours of a corner pair as
  * ONE 16-byte record) is appended to the region of its 64-KB gradient bin, then each bin is accumulated in LDS in 64-bit fixed point and
- * added to the table (see hashgrid.hip).  fp32 contributions throughout; a level that receives a non-finite
- * contribution is filled with NaN (what the float atomics of the reference would have left in the table).
+ * added to the table (see hashgrid.hip).  fp32 contributions throughout; a non-finite contribution bypasses the
+ * records and is added to the table with float atomics, so the inf / NaN lands on exactly the entries the reference's
+ * atomicAdd would have put it on (and nowhere else).
  * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
  * dx_plane_rows = P*n); dout_half != 0: binary16 pairs (see mi3d_grid_encode_points_planes).
  * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
@@ -216,9 +217,11 @@ int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint
  * hold binary16 pairs, half_mode only - applies to x and, in the backward, to dx alike); out [n, dim_out] fp32.
  * half_mode != 0 reproduces torch.autocast(float16) around the stack (nerf/utils.py:979): inputs, weights, biases
  * and every layer output are rounded to binary16, products accumulate in fp32 (v_mfma_f32_32x32x16_f16);
- * half_mode == 0 is exact fp32 (v_mfma_f32_32x32x2_f32).  Supported shape: dim_in 32, dim_hidden 64, dim_out 4,
- * three layers (what network_tcnn.py:67 builds for the default 16-level grid); anything else returns
- * hipErrorInvalidValue - ask mi3d_mlp_supported() first. */
+ * half_mode == 0 is exact fp32 (v_mfma_f32_32x32x2_f32).  Supported shapes - every one the reference's MLP class can
+ * build around this field (network_tcnn.py:37-45,67 takes num_layers and hidden_dim; BASELINE config 1 is 8 -> 32 -> 4):
+ * dim_in even, 2..32 (= 2 x grid levels), dim_hidden 32 or 64, dim_out 4, two or three layers.  TWO layers are
+ * requested by passing W2 == b2 == NULL (and dW2 == db2 == NULL in the backward): y = W3 relu(W1 x + b1) + b3.
+ * Anything else returns hipErrorInvalidValue - ask mi3d_mlp_supported() first. */
 int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, uint32_t num_layers);
 int mi3d_mlp_forward(const void *x, uint32_t x_plane_rows, int planes_half, uint32_t n, const float *W1,
                      const float *b1, const float *W2, const float *b2,

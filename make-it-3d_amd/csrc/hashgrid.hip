@@ -749,9 +749,10 @@ __host__ __device__ inline uint32_t emit_wave_words(uint32_t n_bins) {  // 32-bi
     return 4u * kMergeSlots + kMergeSlots + ((n_bins + 1u) & ~1u);
 }
 
-__global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
+template <bool HP>
+__global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
-                                                             uint32_t n_rows, int planes_half,
+                                                             uint32_t n_rows, int /*HP*/,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
                                                              uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
                                                              uint32_t waves_b, uint32_t fine_level_major,
@@ -823,13 +824,13 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
             // (unconditional loads from clamped rows - a predicated load makes the compiler wait for it on the spot; what
             // an invalid lane or a point >= P fetched is never looked at)
             const size_t prow = (size_t)l * plane_rows + (valid ? s : s_end - 1u);
-            uint32_t raw0[kMaxPts], raw1[kMaxPts];
-            if (planes_half) {
+            uint32_t raw0[kMaxPts], raw1[HP ? 1 : kMaxPts];
+            if (HP) {
 #pragma unroll
                 for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
                     const uint32_t kc = k < ps.P ? k : ps.P - 1u;
                     raw0[k] = reinterpret_cast<const uint32_t *>(dplanes)[prow + (size_t)kc * n_rows];
-                    raw1[k] = 0u;
+                    raw1[0] = 0u;
                 }
             } else {
 #pragma unroll
@@ -849,10 +850,10 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                 bool bad = false;
 #pragma unroll
                 for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
-                    const float dx = planes_half ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] & 0xFFFFu))
+                    const float dx = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] & 0xFFFFu))
                                                  : __uint_as_float(raw0[k]);
-                    const float dy = planes_half ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] >> 16))
-                                                 : __uint_as_float(raw1[k]);
+                    const float dy = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] >> 16))
+                                                 : __uint_as_float(raw1[HP ? 0 : k]);
                     if (valid && k < ps.P) {
                         bad |= !(fabsf(dx) <= 3.4028234663852886e38f && fabsf(dy) <= 3.4028234663852886e38f);
                         tmax = fmaxf(tmax, fmaxf(fabsf(dx), fabsf(dy)));
@@ -969,8 +970,8 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                         const uint32_t p = p0 + c;  // uniform
                         uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
-                        for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[k] : r1; }
-                        const float2 d = planes_half
+                        for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
+                        const float2 d = HP
                             ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                           (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                             : make_float2(__uint_as_float(r0), __uint_as_float(r1));
@@ -1057,30 +1058,95 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-            } else
-            for (uint32_t p = 0; p < ps.P; ++p) {
-                if (merge && (p == 0u || p == ps.P0)) {  // a new group of stencil points: around x, then around x2
-                    flush_group();
-                    float qb[3];
-                    const int which = p < ps.P0 ? 0 : 1;
+            } else if (merge && !dead) {
+                // ---- coarse level.  The stencil points of one base position mostly share its cell: those are summed in
+                // registers (acc0 / acc1, flushed into the gather table when the group ends); a point that left the
+                // base cell goes to the gather table directly - and that path, 8 probes and 16 atomics, executes for
+                // the whole wave as soon as ONE lane needs it, i.e. practically for every neighbour point.  So the +eps
+                // and -eps neighbours of an axis are evaluated TOGETHER: below ~0.5 cells of epsilon a sample cannot
+                // leave its cell on both sides, one gather serves the pair (a second one runs only if some lane did).
+                auto eval_point = [&](uint32_t p, uint32_t &cx, uint32_t &cy, uint32_t &cz, float (&v0)[8], float (&v1)[8])
+                    __attribute__((always_inline)) {
+                    uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) {
-                        if (ps.mode == 0) {
-                            qb[dd] = base[which][dd];
-                        } else {
-                            const float w = clampf(base[which][dd], -ps.bound, ps.bound);
-                            qb[dd] = (w + ps.bound) / (2.0f * ps.bound);
+                    for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
+                    const float2 d = HP
+                        ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
+                                      (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
+                        : make_float2(__uint_as_float(r0), __uint_as_float(r1));
+                    float q[3];
+                    point_of(ps, base, p, q);
+                    float fx, fy, fz;
+                    grid_cell(q[0], L.scale, cx, fx);
+                    grid_cell(q[1], L.scale, cy, fy);
+                    grid_cell(q[2], L.scale, cz, fz);
+                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;  // forward's product order
+                    const float wk[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) { v0[k] = wk[k] * d.x; v1[k] = wk[k] * d.y; }
+                    return valid && (d.x != 0.f || d.y != 0.f);
+                };
+                for (uint32_t p = 0; p < ps.P;) {
+                    if (p == 0u || p == ps.P0) {  // a new group of stencil points: around x, then around x2
+                        flush_group();
+                        float qb[3];
+                        const int which = p < ps.P0 ? 0 : 1;
+#pragma unroll
+                        for (int dd = 0; dd < 3; ++dd) {
+                            if (ps.mode == 0) {
+                                qb[dd] = base[which][dd];
+                            } else {
+                                const float w = clampf(base[which][dd], -ps.bound, ps.bound);
+                                qb[dd] = (w + ps.bound) / (2.0f * ps.bound);
+                            }
+                        }
+                        float unused;
+                        grid_cell(qb[0], L.scale, bx, unused);
+                        grid_cell(qb[1], L.scale, by, unused);
+                        grid_cell(qb[2], L.scale, bz, unused);
+                    }
+                    const bool paired = p != 0u && p + 1u < ps.P && p + 1u != ps.P0;
+                    uint32_t ax, ay, az, cx2 = 0, cy2 = 0, cz2 = 0;
+                    float a0[8], a1[8], b0[8], b1[8];
+                    const bool has_a = eval_point(p, ax, ay, az, a0, a1);
+                    const bool same_a = has_a && ax == bx && ay == by && az == bz;
+                    bool has_b = false, same_b = false;
+                    if (paired) {
+                        has_b = eval_point(p + 1u, cx2, cy2, cz2, b0, b1);
+                        same_b = has_b && cx2 == bx && cy2 == by && cz2 == bz;
+                    }
+                    if (__ballot(same_a || same_b) != 0ull) {
+                        acc_any = true;
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) {
+                            acc0[k] += (same_a ? a0[k] : 0.f) + (same_b ? b0[k] : 0.f);
+                            acc1[k] += (same_a ? a1[k] : 0.f) + (same_b ? b1[k] : 0.f);
                         }
                     }
-                    float unused;
-                    grid_cell(qb[0], L.scale, bx, unused);
-                    grid_cell(qb[1], L.scale, by, unused);
-                    grid_cell(qb[2], L.scale, bz, unused);
+                    const bool ex_a = has_a && !same_a, ex_b = has_b && !same_b;
+                    if (__ballot(ex_a || ex_b) != 0ull) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) {  // in place (registers): zeros are skipped by gather8
+                            a0[k] = ex_a ? a0[k] : (ex_b ? b0[k] : 0.f);
+                            a1[k] = ex_a ? a1[k] : (ex_b ? b1[k] : 0.f);
+                        }
+                        gather8(ex_a ? ax : cx2, ex_a ? ay : cy2, ex_a ? az : cz2, a0, a1);
+                        const bool both = ex_a && ex_b;
+                        if (__ballot(both) != 0ull) {
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) { b0[k] = both ? b0[k] : 0.f; b1[k] = both ? b1[k] : 0.f; }
+                            gather8(cx2, cy2, cz2, b0, b1);
+                        }
+                    }
+                    p += paired ? 2u : 1u;
                 }
+            } else
+            for (uint32_t p = 0; p < ps.P; ++p) {  // fine levels without the pair structure, and tiles with a non-finite gradient
                 uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
-                for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[k] : r1; }
-                const float2 d = planes_half
+                for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
+                const float2 d = HP
                     ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                   (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                     : make_float2(__uint_as_float(r0), __uint_as_float(r1));
@@ -1109,7 +1175,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                     }
                     continue;
                 }
-                if (dead) {  // a tile with a non-finite gradient: plain float atomics, entry by entry
+                {   // (merge && dead) a tile with a non-finite gradient: plain float atomics, entry by entry
                     if (has) {
 #pragma unroll 1
                         for (uint32_t k = 0; k < 8; ++k) {  // (rare path: kept rolled, it must not cost the kernel registers)
@@ -1119,20 +1185,6 @@ __global__ __launch_bounds__(kWave *kWaves) void k_bin_emit(PointSet ps, uint32_
                             unsafeAtomicAdd(dst + 1, wkk * d.y);
                         }
                     }
-                    continue;
-                }
-                // coarse level: the stencil points of one base position mostly share its cell - those are summed in
-                // registers first (acc0 / acc1, flushed when the group ends); the others go to the gather table directly
-                const bool same = has && cx == bx && cy == by && cz == bz;
-                if (same) {
-                    acc_any = true;
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) { acc0[k] += wk[k] * d.x; acc1[k] += wk[k] * d.y; }
-                } else if (has) {
-                    float v0[8], v1[8];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) { v0[k] = wk[k] * d.x; v1[k] = wk[k] * d.y; }
-                    gather8(cx, cy, cz, v0, v1);
                 }
             }
             if (merge) flush_group();
@@ -1459,7 +1511,9 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     float *level_max = reinterpret_cast<float *>(counts + plan.total_counts);
     const size_t lds = (size_t)kWaves * emit_wave_words(plan.n_bins) * sizeof(uint32_t);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(dout_half ? reinterpret_cast<const void *>(k_bin_emit<true>)
+                                            : reinterpret_cast<const void *>(k_bin_emit<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const size_t lds_reduce = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
     // per call: the attribute is per device and the call is a host-side table write (no static, re-entrant)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1477,9 +1531,17 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
         if (fine_waves + coarse_waves)
-            hipLaunchKernelGGL(k_bin_emit, dim3((fine_waves + coarse_waves) / kWaves), dim3(kWave * kWaves), lds, st, ps,
-                               (uint32_t)s0, s1, dout_planes, plane_rows, n, dout_half, T, plan, merge_levels, fine_mask, fine_waves,
-                               coarse_mask, coarse_waves, emit_order, reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
+        {
+            const dim3 eg((fine_waves + coarse_waves) / kWaves), eb(kWave * kWaves);
+            if (dout_half)
+                hipLaunchKernelGGL(k_bin_emit<true>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, 1, T,
+                                   plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
+                                   reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
+            else
+                hipLaunchKernelGGL(k_bin_emit<false>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, 0, T,
+                                   plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
+                                   reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
+        }
         const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
         plan_reduce_splits(plan, T, n_split, merge_levels);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_reduce_wgs), dim3(kWave * kReduceWaves), lds_reduce, st, arena,

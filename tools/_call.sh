@@ -1,12 +1,13 @@
 set -x
 cd /root/repo
 export TMPDIR=/tmp
-python -m pytest tests/test_fullsize_gpu.py tests/test_reference_glue_gpu.py tests/test_rccl_gpu.py tests/test_grid_points_gpu.py tests/test_hashgrid_gpu.py -x -q 2>&1 | tail -25 > gpurun_out/c6_tests.log
-tail -5 gpurun_out/c6_tests.log
-python tools/kbench.py --what encode --half-planes --out gpurun_out/kb_encode_r03c.json > gpurun_out/kb_encode_r03c.log 2>&1
-for cw in 3 4 5 8; do python tools/kbench.py --what encode1 --half-planes --dev 12=$cw --out gpurun_out/kb_enc_cw$cw.json 2>&1 | grep encode_ms; done
-# un-profiled A/B of the scatter: previous library vs this one, 56 and 120 GiB caps
-for cap in 56 120; do for v in old new; do
-  if [ $v = old ]; then export MI3D_LIB=/root/repo/tools/bin/libmi3d_dev_oldscatter.so; else export MI3D_LIB=/root/repo/tools/bin/libmi3d_dev.so; fi
-  MI3D_SCATTER_WORKSPACE_GB=$cap python tools/kbench.py --what scatter13 --half-planes --iters 4 --out gpurun_out/kb_ab_${v}_$cap.json 2>&1 | grep scatter_fp32
-done; done
+python -m pytest tests/test_sds_step_gpu.py -x -q 2>&1 | tail -3
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r03_c2_dense.json 2> gpurun_out/bench_r03_c2_dense.err
+tail -6 gpurun_out/bench_r03_c2_dense.err
+for w in c2_pruned c4_views c5_refine; do
+  python bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-reference-shaped > gpurun_out/bench_r03_$w.json 2> gpurun_out/bench_r03_$w.err
+  tail -2 gpurun_out/bench_r03_$w.err
+done
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_c4 -- python bench.py --workload c4_views --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/bench_c4_prof.err
+python tools/trace_sum.py gpurun_out/prof_c4 --out gpurun_out/kernel_stats_r03_c4_views.csv | head -8
+rm -rf gpurun_out/prof_c4

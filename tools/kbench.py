@@ -166,6 +166,20 @@ def main():
         tune(5, -1)
         res["scatter13_dense_ms_by_level_mask"] = out
         del g
+    if "scatter_roles" in what:  # each role of the emit alone (dev level mask) against its wave count
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        out = {}
+        for name, mk, knob, values in (("fine_8_15", 0xFF00, T_EMIT_FINE, (768, 1024, 1536, 2048, 3072)),
+                                        ("coarse_0_7", 0x00FF, T_EMIT_COARSE, (2048, 4096, 8192, 16384))):
+            tune(5, mk)
+            for v in values:
+                tune(knob, v)
+                out[f"{name}_waves{v}"] = timeit(lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg,
+                                                                                  2 * 3 ** 0.5 / 1024, 12196240), 2)
+            tune(knob, -1)
+        tune(5, -1)
+        res["scatter13_dense_role_ms_by_waves"] = out
+        del g
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)

@@ -15,16 +15,17 @@ import json
 import os
 import sys
 
-FAMILIES = {
-    "k_grid_encode_planes": "k_grid_encode_planes", "k_mlp_forward": "k_mlp_forward", "k_mlp_backward": "k_mlp_backward",
-    "k_bin_emit16": "k_bin_emit16", "k_bin_emit": "k_bin_emit(", "k_bin_reduce": "k_bin_reduce",
-    "k_head_forward": "k_head_forward", "k_head_backward": "k_head_backward", "k_march_train": "k_march_train",
-    "k_composite_train_fwd": "k_composite_train_fwd", "k_composite_train_bwd": "k_composite_train_bwd",
-}
+FAMILIES = [   # (family key, substring of the kernel name); round 3's generic MLP kernels keep the family names
+    ("k_grid_encode_planes", "k_grid_encode_planes"), ("k_mlp_forward", "k_mlp_forward"), ("k_mlp_forward", "k_mlp_fwd_g"),
+    ("k_mlp_backward", "k_mlp_backward"), ("k_mlp_backward", "k_mlp_bwd_g"),
+    ("k_bin_emit16", "k_bin_emit16"), ("k_bin_emit", "k_bin_emit("), ("k_bin_reduce", "k_bin_reduce"),
+    ("k_head_forward", "k_head_forward"), ("k_head_backward", "k_head_backward"), ("k_march_train", "k_march_train"),
+    ("k_composite_train_fwd", "k_composite_train_fwd"), ("k_composite_train_bwd", "k_composite_train_bwd"),
+]
 
 
 def family(kernel_name):
-    for fam, sub in FAMILIES.items():
+    for fam, sub in FAMILIES:
         if sub in kernel_name or (fam == "k_bin_emit" and "k_bin_emit" in kernel_name and "emit16" not in kernel_name):
             return fam
     return None
