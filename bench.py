@@ -445,8 +445,7 @@ def main():
                 if args.refresh_every > 0 and clock["i"] % args.refresh_every == 0:
                     refresh()
                 clock["i"] += 1
-                if sync is not None:
-                    bucket.zero()
+                # (the step's own optimizer.zero_grad clears the gradients, which ARE the flat bucket's views)
                 sds_step.sds_train_step(the_model, guidance, text_z, the_optimizer, the_scaler, ro, rd, ds, wl["H"],
                                         wl["W"], opt, sds_backward=schedule, t=t_fixed, grad_sync=sync)
         step.clock = clock

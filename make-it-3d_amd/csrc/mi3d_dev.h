@@ -26,5 +26,7 @@ enum : int {
     MI3D_T_REPLICAS = 9,
     MI3D_T_EMIT_ORDER = 10,
     MI3D_T_MLP_FWD_WGS_PER_CU = 11,
-    MI3D_T_ENCODE_COARSE_WGS_PER_CU = 12,        // 1: the fine emit role walks level-major (one level's regions open at a time)
+    MI3D_T_ENCODE_COARSE_WGS_PER_CU = 12,
+    MI3D_T_MARCH_RPW_MIN = 13,
+    MI3D_T_MARCH_WAVES = 14,        // 1: the fine emit role walks level-major (one level's regions open at a time)
 };

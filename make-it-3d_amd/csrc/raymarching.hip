@@ -3,10 +3,11 @@
 // Implements Part 1 of include/mi3d.h - the 13 entry points the reference binds in
 // /root/reference/raymarching/src/bindings.cpp:5-23 - as native HIP:
 //
-//  * march_rays_train : one wave = 64 rays, one workgroup = one wave (N/64 workgroups so a 128x128
-//    view already fills the 256 CUs).  Count pass -> wave64 inclusive scan of the per-ray sample
-//    counts -> ONE atomic per wave reserves the slab for all 64 rays (the reference issues two
-//    global atomics per ray, raymarching.cu:405-406) -> write pass.  rays[] rows are in ray order.
+//  * march_rays_train : persistent waves, one wave = 64 rays at a time (a 128x128 view = 256 batches already
+//    fills the 256 CUs).  Count pass -> wave64 inclusive scan of the per-ray sample counts -> ONE atomic
+//    per wave reserves the slab for all 64 rays (the reference issues two global atomics per ray,
+//    raymarching.cu:405-406) -> write pass through per-ray LDS rings, flushed as whole rows in flat order.
+//    rays[] rows are in ray order.
 //  * composite_rays_train fwd/bwd : one wave per RAY.  Lanes load 64 consecutive samples of the ray
 //    (coalesced; the reference reads with a stride of one ray length between lanes), transmittance
 //    is a wave64 multiplicative prefix scan, early termination is a ballot + first-set-lane, sums are
@@ -22,6 +23,7 @@
 
 #include "../../include/mi3d.h"
 #include "mi3d_common.h"
+#include "mi3d_dev.h"
 
 using namespace mi3d;
 
@@ -32,6 +34,7 @@ constexpr int kWave = 64;
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_status() { return (int)hipGetLastError(); }
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+__device__ __forceinline__ uint32_t cdiv_dev(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- wave64 primitives
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
@@ -144,65 +147,115 @@ __global__ void k_packbits(const float4 *__restrict__ grid, uint32_t N, float th
 
 // ---------------------------------------------------------------- training march
 
+// Persistent waves, LDS-staged sample compaction, whole-row stores.  A wave takes batches of 64 rays (lane = ray, batch
+// w, w + W, ... of the W waves of the launch) and walks each batch twice, as the reference does (raymarching.cu:335-479:
+// the slab of a ray must be known before its first sample can be written, and the walk itself is the reference's
+// arithmetic, step by step - the integer voxel / Morton / bit indices are bit-exact).  What is different is where the
+// samples go: every occupied step appends {x, y, z, dt, delta} to its lane's ring in LDS; as soon as one ring is full the
+// wave flushes ALL staged samples in flat order - consecutive lanes write consecutive ROWS of a ray's slab with one
+// 12-byte (xyz, dirs) / 8-byte (deltas) store each - instead of every lane trickling 4-byte stores into its own slab
+// (64 scattered dwords per instruction, 8 instructions per step).
+constexpr int kRing = 8;  // staged samples per ray
+
+struct Row3 { float a, b, c; };
+struct Row2 { float a, b; };
+
 __global__ __launch_bounds__(kWave) void k_march_train(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ bits,
     float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
     const float *__restrict__ nears, const float *__restrict__ fars, float *__restrict__ xyzs,
     float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *counter,
-    const float *__restrict__ noises) {
+    const float *__restrict__ noises, uint32_t rpw /* rays per wave: 16, 32 or 64 */) {
+    __shared__ float ring[kWave * kRing * 5];      // [lane][slot]{x, y, z, dt, delta}
+    __shared__ float rdir[kWave * 3];              // the lane's ray direction
+    __shared__ uint32_t rdst[kWave], rpfx[kWave];  // first row of the lane's staged samples; its first flat index
+    __shared__ uint8_t owner[kWave * kRing];       // flat staged index -> lane
     const int lane = lane_id();
-    const uint32_t n = blockIdx.x * kWave + lane;
-    const bool live = n < N;
-
     MarchGrid g;
     march_grid_init(g, bits, bound, dt_gamma, max_steps, C, H);
-    MarchRay r;
-    float far = 0.f, t0 = 0.f;
-    if (live) {
-        march_ray_init(r, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
-        far = fars[n];
-        t0 = march_t0(nears[n], noises[n], g);
-    }
+    // Small views run with FEWER rays per wave (the other lanes only help in the flush) so that every SIMD has a wave to
+    // issue from - see mi3d_march_rays_train: 16 rays per wave at C2 = 1024 waves.
+    const uint32_t n_batches = cdiv_dev(N, rpw);
 
-    // pass 1: how many occupied steps does this ray take?
-    uint32_t count = 0;
-    if (live) {
-        float t = t0, x, y, z, dt;
-        while (t < far && count < max_steps)
-            if (march_step(r, g, t, x, y, z, dt)) ++count;
-    }
+    for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+        const uint32_t n = batch * rpw + lane;
+        const bool live = (uint32_t)lane < rpw && n < N;
+        MarchRay r;
+        float far = 0.f, t0 = 0.f;
+        if (live) {
+            march_ray_init(r, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+            far = fars[n];
+            t0 = march_t0(nears[n], noises[n], g);
+        }
 
-    // slab reservation: wave scan + one atomic per wave (counter[0] += samples, counter[1] += rays)
-    const uint32_t incl = wave_scan_add_u32(count, lane);
-    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
-    uint32_t base = 0;
-    if (lane == 0) {
-        base = (uint32_t)atomicAdd(counter, (int)wave_total);
-        const uint32_t rays_here = (N - blockIdx.x * kWave) < (uint32_t)kWave ? (N - blockIdx.x * kWave) : (uint32_t)kWave;
-        atomicAdd(counter + 1, (int)rays_here);
-    }
-    base = __shfl(base, 0, kWave);
-    const uint32_t offset = base + incl - count;
-    if (!live) return;
+        // pass 1: how many occupied steps does this ray take?
+        uint32_t count = 0;
+        if (live) {
+            float t = t0, x, y, z, dt;
+            while (t < far && count < max_steps)
+                if (march_step(r, g, t, x, y, z, dt)) ++count;
+        }
 
-    rays[(size_t)n * 3] = (int32_t)n;
-    rays[(size_t)n * 3 + 1] = (int32_t)offset;
-    rays[(size_t)n * 3 + 2] = (int32_t)count;
-    if (count == 0 || offset + count > M) return;  // overflowing rays are dropped, not an error
+        // slab reservation: wave scan + one atomic per wave (counter[0] += samples, counter[1] += rays)
+        const uint32_t incl = wave_scan_add_u32(count, lane);
+        const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = (uint32_t)atomicAdd(counter, (int)wave_total);
+            const uint32_t rays_here = (N - batch * rpw) < rpw ? (N - batch * rpw) : rpw;
+            atomicAdd(counter + 1, (int)rays_here);
+        }
+        base = __shfl(base, 0, kWave);
+        const uint32_t offset = base + incl - count;
+        if (live) {
+            rays[(size_t)n * 3] = (int32_t)n;
+            rays[(size_t)n * 3 + 1] = (int32_t)offset;
+            rays[(size_t)n * 3 + 2] = (int32_t)count;
+        }
+        // overflowing rays are dropped, not an error (raymarching.cu:416)
+        bool active = live && count != 0 && offset + count <= M;
 
-    // pass 2: replay the same walk and emit the samples
-    float *px = xyzs + (size_t)offset * 3, *pd = dirs + (size_t)offset * 3, *pl = deltas + (size_t)offset * 2;
-    float t = t0, last_t = t0, x, y, z, dt;
-    uint32_t step = 0;
-    while (t < far && step < count) {
-        if (march_step(r, g, t, x, y, z, dt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-            pl[0] = dt;
-            pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2;
-            ++step;
+        // pass 2: replay the same walk; samples go through the rings
+        if (active) { rdir[lane * 3] = r.dx; rdir[lane * 3 + 1] = r.dy; rdir[lane * 3 + 2] = r.dz; }
+        float t = t0, last_t = t0;
+        uint32_t step = 0, written = 0, fill = 0;
+        while (__any(active) || __any(fill != 0u)) {
+            // lockstep walk until one ring is full (or nobody is left walking)
+            while (__any(active) && !__any(fill == (uint32_t)kRing)) {
+                if (active) {
+                    if (t < far && step < count) {
+                        float x, y, z, dt;
+                        if (march_step(r, g, t, x, y, z, dt)) {
+                            float *slot = ring + ((size_t)lane * kRing + fill) * 5;
+                            slot[0] = x; slot[1] = y; slot[2] = z; slot[3] = dt; slot[4] = t - last_t;
+                            last_t = t;
+                            ++fill;
+                            ++step;
+                        }
+                    } else {
+                        active = false;
+                    }
+                }
+            }
+            // flush: flat index i -> (owner lane, slot); consecutive i of one owner are consecutive rows of its slab
+            const uint32_t fincl = wave_scan_add_u32(fill, lane);
+            const uint32_t total = __shfl(fincl, kWave - 1, kWave);
+            const uint32_t pfx = fincl - fill;
+            rdst[lane] = offset + written;
+            rpfx[lane] = pfx;
+            for (uint32_t j = 0; j < fill; ++j) owner[pfx + j] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < total; i += kWave) {
+                const uint32_t o = owner[i], j = i - rpfx[o];
+                const size_t row = (size_t)rdst[o] + j;
+                const float *slot = ring + ((size_t)o * kRing + j) * 5;
+                *reinterpret_cast<Row3 *>(xyzs + row * 3) = Row3{slot[0], slot[1], slot[2]};
+                *reinterpret_cast<Row3 *>(dirs + row * 3) = Row3{rdir[o * 3], rdir[o * 3 + 1], rdir[o * 3 + 2]};
+                *reinterpret_cast<Row2 *>(deltas + row * 2) = Row2{slot[3], slot[4]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            written += fill;
+            fill = 0;
         }
     }
 }
@@ -600,8 +653,18 @@ int mi3d_march_rays_train(const float *rays_o, const float *rays_d, const uint8_
                           const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                           const float *noises, void *stream) {
     if (N == 0) return 0;
-    hipLaunchKernelGGL(k_march_train, dim3(cdiv(N, kWave)), dim3(kWave), 0, as_stream(stream), rays_o, rays_d, grid,
-                       bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises);
+    // rays per wave.  The walk is ~150 instructions per step in a dependent chain, so a wave advances at one wave's issue
+    // rate whatever its lane count: a view of 16 384 rays as 256 full waves would use one SIMD in four.  Halve the rays
+    // per wave until every SIMD has a wave (1024), down to 16 rays each; more waves than SIMDs only add instructions
+    // (measured at C2, tools/march_bench.py: 64 rays per wave 0.75 ms, 16: 0.69, 8: 0.79, 4: 1.48).  One wave's worth of
+    // rays stays one wave (its slab order is then the ray order, which tests that compare two runs row by row rely on).
+    uint32_t rpw = kWave;
+    const uint32_t floor_rpw = (uint32_t)MI3D_TUNE(MI3D_T_MARCH_RPW_MIN, 16), want = (uint32_t)MI3D_TUNE(MI3D_T_MARCH_WAVES, 1024);
+    while (N > (uint32_t)kWave && rpw > floor_rpw && cdiv(N, rpw) < want) rpw >>= 1;
+    const uint32_t batches = cdiv(N, rpw), resident = 256u * 16u;  // persistent beyond 16 waves per CU
+    hipLaunchKernelGGL(k_march_train, dim3(batches < resident ? batches : resident), dim3(kWave), 0, as_stream(stream),
+                       rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                       counter, noises, rpw);
     return launch_status();
 }
 

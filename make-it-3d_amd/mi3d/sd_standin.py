@@ -368,10 +368,10 @@ class StableDiffusionStandIn(nn.Module):
     def _unet_forward(self, x, t, ctx):
         """U-Net noise prediction; on the GPU through a captured hipGraph (torch.cuda.CUDAGraph) keyed on the shapes
         and the autocast state, eagerly if capture is unavailable."""
-        if not (self.graph_unet and x.is_cuda):
+        if not (getattr(self, "graph_unet", False) and x.is_cuda):  # (objects assembled without __init__: eager)
             return self.unet(x, t, encoder_hidden_states=ctx)
         key = (tuple(x.shape), x.dtype, tuple(ctx.shape), tuple(t.shape), torch.is_autocast_enabled("cuda"))
-        if self._graph is None or self._graph[0] != key:
+        if getattr(self, "_graph", None) is None or self._graph[0] != key:
             try:
                 gx, gt, gc = x.clone(), t.clone(), ctx.clone()
                 side = torch.cuda.Stream(device=x.device)
