@@ -65,7 +65,7 @@ struct F16 {
     }
     // one K-block product = kSteps matrix instructions; issuing step s of several products before step s + 1 of any
     // keeps consecutive MFMAs on different accumulators
-    static constexpr int kSteps = 2;
+    [[maybe_unused]] static constexpr int kSteps = 2;
     __device__ static __forceinline__ void mma_step(f32x16 &acc, const KB &a, const KB &b, int s) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[s], b.v[s], acc, 0, 0, 0);
     }
@@ -307,7 +307,7 @@ template <class P> __device__ __forceinline__ typename P::KB rows_kb(const float
 }
 // binary16 planes: the 8 dwords a lane fetches ARE its K-block (pair j = features 2j, 2j+1 of this lane-half) - the
 // backward keeps them as bit patterns while they are in flight and re-interprets them, no conversion either way
-__device__ __forceinline__ void load_rows_half(const float *__restrict__ x, size_t row, size_t n, int h,
+[[maybe_unused]] __device__ __forceinline__ void load_rows_half(const float *__restrict__ x, size_t row, size_t n, int h,
                                                size_t plane_rows, uint32_t (&u)[8]) {
     row = row < n ? row : n - 1;
 #pragma unroll

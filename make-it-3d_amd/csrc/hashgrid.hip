@@ -258,6 +258,58 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
     }
 }
 
+// The coarsest levels from LDS.  Levels whose tables fit a CU's LDS together (the default grid: level 0 = 4096 entries,
+// level 1 = 12 167: 130 KB of 160) are staged once per workgroup - one 1024-thread workgroup per CU, persistent over the
+// tiles - and every corner is a ds_read_b64: same cells, same weights, same order of the eight fused multiply-adds as
+// k_grid_encode_planes, so the planes are bit-identical; what changes is that 8 corners cost 16 LDS cycles instead of 4-8
+// vector-memory instructions of 16+ cycles each (these levels ran at 0.84 ms each from the L1).
+constexpr int kLdsWaves = 16;
+template <bool NT>
+__global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(PointSet ps, uint32_t n,
+                                                                             const float2 *__restrict__ table, GridTable T,
+                                                                             uint32_t n_lds_levels,
+                                                                             float *__restrict__ planes, int out_half) {
+    extern __shared__ float2 lds_tab[];
+    const uint32_t total = T.level[n_lds_levels - 1].offset + T.level[n_lds_levels - 1].size;  // levels are contiguous from 0
+    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) lds_tab[i] = table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const size_t rows_total = (size_t)n * ps.P;
+    for (uint32_t tile = blockIdx.x * kLdsWaves + wave; tile < n_tiles; tile += gridDim.x * kLdsWaves) {
+        const uint32_t s = tile * kTile + lane;
+        if (s >= n) continue;
+        float base[2][3];
+        load_bases(ps, s, true, base);
+        for (uint32_t l = 0; l < n_lds_levels; ++l) {
+            const GridLevel L = T.level[l];
+            const float2 *lvl = lds_tab + L.offset;
+            const size_t plane0 = (size_t)l * rows_total;
+            for (uint32_t p = 0; p < ps.P; ++p) {
+                float q[3];
+                point_of(ps, base, p, q);
+                uint32_t cx, cy, cz;
+                float fx, fy, fz;
+                grid_cell(q[0], L.scale, cx, fx);
+                grid_cell(q[1], L.scale, cy, fy);
+                grid_cell(q[2], L.scale, cz, fz);
+                float2 v[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) v[k] = lvl[grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))];
+                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
+                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+                const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
+                store_plane_pair<NT>(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
+            }
+        }
+    }
+}
+
 // Relative cost of one tile of a level, as a function of x = (marching step) x (level scale) = how many cells of the
 // level two consecutive samples of a ray are apart: the measured per-level times above, tabulated against x (C2: step
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
@@ -277,12 +329,13 @@ inline uint32_t encode_level_wgs_per_cu(double x, uint32_t coarse, uint32_t fine
 
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
 inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level,
-                                   uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd) {
+                                   uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd, uint32_t first_level = 0) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale);
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
+        if (l < first_level) cost[l] = 0.0;  // served from LDS by k_grid_encode_planes_lds
         total += cost[l];
     }
     const double share = total / kXcds;
@@ -532,6 +585,14 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
                            merge_levels, level_mask & ~runs_mask, plane_rows, planes_half, n_rep, rep_stride, grad_params);
     return (int)hipGetLastError();
 }
+
+// The record path sums a tile in the gather table only where it pays: on levels whose cells are at least this many
+// marching steps long (divided by default_merge_levels' own 1.05); the others emit per-point x-pair records.  3 steps =
+// levels 0-7 at C2.  The gathered role is bound by its instruction stream, the record role by bytes, and in a real step
+// (half the binary16 gradient pairs are zeros: fewer records, same instructions) the gathered role is the one the launch
+// waits for, so a threshold of 4.2 steps (level 7 -> records) was measured: a whole field iteration 89.5 -> 86.4 ms
+// (5.8: 87.5, 8.0: 92.4), but the dense-gradient scatter 58 -> 66 ms and 8 GiB more arena - not adopted.
+inline float merge_steps() { return (float)MI3D_TUNE(MI3D_T_MERGE_STEPS_X10, 30) / 10.5f; }
 
 // levels whose cells are longer than one marching step `step01` (in [0,1] units) try to merge neighbours
 uint32_t default_merge_levels(const GridTable &T, float step01) {
@@ -1422,12 +1483,33 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
     const uint32_t wgs_fine = need < 32 * fine_cu ? need : 32 * fine_cu;        // 32 CUs per XCD; persistent beyond
     uint32_t wgs_coarse = need < 32 * coarse_cu ? need : 32 * coarse_cu;
     if (wgs_coarse < wgs_fine) wgs_coarse = wgs_fine;
-    const EncodePlan plan = make_encode_plan(T, tiles, step01, MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1), wgs_coarse, wgs_fine);
-    const uint32_t per_xcd = wgs_coarse;
-    const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     const float2 *tab = reinterpret_cast<const float2 *>(params);
     float *out = reinterpret_cast<float *>(out_planes);
     hipStream_t st = as_stream(stream);
+    // the longest prefix of levels whose tables fit the LDS of a CU together goes through the LDS kernel
+    const int only_level = MI3D_TUNE(MI3D_T_ENCODE_ONLY_LEVEL, -1);
+    uint32_t n_lds = 0;
+    size_t lds_bytes = 0;
+    while (n_lds < T.n_levels && (size_t)(T.level[n_lds].offset + T.level[n_lds].size) * sizeof(float2) <= (size_t)150 * 1024) {
+        lds_bytes = (size_t)(T.level[n_lds].offset + T.level[n_lds].size) * sizeof(float2);
+        ++n_lds;
+    }
+    if (MI3D_TUNE(MI3D_T_ENCODE_LDS_LEVELS, -1) >= 0) {  // dev: force the count (0 = off)
+        n_lds = (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_LDS_LEVELS, -1) < n_lds ? (uint32_t)MI3D_TUNE(MI3D_T_ENCODE_LDS_LEVELS, -1) : n_lds;
+        lds_bytes = n_lds ? (size_t)(T.level[n_lds - 1].offset + T.level[n_lds - 1].size) * sizeof(float2) : 0;
+    }
+    if (only_level >= 0) n_lds = 0;
+    if (n_lds > 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grid_encode_planes_lds<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        const uint32_t wgs = (tiles + kLdsWaves - 1) / kLdsWaves;
+        hipLaunchKernelGGL((k_grid_encode_planes_lds<true>), dim3(wgs < 256u ? wgs : 256u), dim3(kWave * kLdsWaves), lds_bytes,
+                           st, ps, n, tab, T, n_lds, out, out_half);
+        if (n_lds == T.n_levels) return (int)hipGetLastError();
+    }
+    const EncodePlan plan = make_encode_plan(T, tiles, step01, only_level, wgs_coarse, wgs_fine, n_lds);
+    const uint32_t per_xcd = wgs_coarse;
+    const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     if ((variant & 3) == 3)
         hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
     else if (variant & 1)
@@ -1459,7 +1541,7 @@ size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, f
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    return bin_workspace_bytes(plan_for(T, n, P, step01, default_merge_levels(T, step01 * (3.0f / 1.05f))));
+    return bin_workspace_bytes(plan_for(T, n, P, step01, default_merge_levels(T, step01 * merge_steps())));
 }
 
 int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
@@ -1479,7 +1561,7 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
     // the record path run-merges only where it pays (cells at least 3 marching steps long); levels with shorter runs
     // emit per-point records (16-byte x-pair records where the level's entries allow it)
     const uint32_t merge_atomic = default_merge_levels(T, step01);
-    const uint32_t merge_levels = default_merge_levels(T, step01 * (3.0f / 1.05f));
+    const uint32_t merge_levels = default_merge_levels(T, step01 * merge_steps());
     const uint32_t plane_rows = n * P;
 
     // the slice: the largest sample count (halving from n) whose record arena fits the workspace
@@ -1559,7 +1641,10 @@ int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    const EncodePlan plan = make_encode_plan(T, (n + kTile - 1) / kTile, step01, -1, 32 * 6, 32 * 3);
+    uint32_t n_lds = 0;  // as mi3d_grid_encode_points_planes: the levels served from LDS are not in the plan
+    while (n_lds < T.n_levels && (size_t)(T.level[n_lds].offset + T.level[n_lds].size) * sizeof(float2) <= (size_t)150 * 1024) ++n_lds;
+    if (n_lds == T.n_levels) n_lds = 0;
+    const EncodePlan plan = make_encode_plan(T, (n + kTile - 1) / kTile, step01, -1, 32 * 6, 32 * 3, n_lds);
     for (uint32_t x = 0; x < kXcds; ++x) {
         n_segments[x] = plan.n_seg[x];
         for (uint32_t i = 0; i < (uint32_t)kMaxSegs; ++i) {
@@ -1580,7 +1665,7 @@ int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
-    const uint32_t merge_levels = default_merge_levels(T, step01 * (3.0f / 1.05f));
+    const uint32_t merge_levels = default_merge_levels(T, step01 * merge_steps());
     uint64_t n_slice = n;  // the same halving mi3d_grid_scatter_binned does
     BinPlan p = plan_for(T, n_slice, P, step01, merge_levels);
     while (n_slice > kWave && bin_workspace_bytes(p) > workspace_bytes) {

@@ -61,6 +61,10 @@ struct MarchGrid {
     float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Hm1;
     int C;
     uint32_t H;
+    // uniform shortcuts that leave every result bit for bit (see march_step): H a power of two -> the reference's
+    // double-precision products by 0.5 and H are exact scalings, done in float; one cascade -> level 0 always
+    bool h_pow2, one_level;
+    float half_H, mip_bound0, mip_rbound0;
 };
 
 MI3D_HD void march_ray_init(MarchRay &r, const float *o, const float *d) {
@@ -81,12 +85,21 @@ MI3D_HD void march_grid_init(MarchGrid &g, const uint8_t *bits, float bound, flo
     g.Hf = (float)H;
     g.Hm1 = (float)(H - 1);
     g.C = (int)C; g.H = H;
+    g.h_pow2 = H >= 2 && (H & (H - 1)) == 0;
+    g.one_level = C == 1;
+    g.half_H = 0.5f * (float)H;
+    g.mip_bound0 = fminf(1.0f, bound);
+    g.mip_rbound0 = 1.0f / g.mip_bound0;
 }
 
 // voxel coordinate along one axis: trunc(clamp(0.5*(p/mb + 1)*H, 0, H-1)).  The reference evaluates the
 // outer product in double; the float fma result times 0.5 and H is re-rounded to float by clamp().
 MI3D_HD int voxel_coord(float p, float mip_rbound, const MarchGrid &g) {
-    const double v = 0.5 * (double)fmaf(p, mip_rbound, 1.0f) * (double)g.H;
+    const float u = fmaf(p, mip_rbound, 1.0f);
+    // H = 2^k: 0.5 * u * H is u scaled by a power of two - exact in float and in double alike, so the float product IS
+    // the double product rounded to float (u is O(1): no overflow, no underflow)
+    if (g.h_pow2) return (int)clampf(u * g.half_H, 0.0f, g.Hm1);
+    const double v = 0.5 * (double)u * (double)g.H;
     return (int)clampf((float)v, 0.0f, g.Hm1);
 }
 
@@ -98,16 +111,20 @@ MI3D_HD bool march_step(const MarchRay &r, const MarchGrid &g, float &t, float &
     z = clampf(fmaf(t, r.dz, r.oz), -g.bound, g.bound);
     dt = clampf(t * g.dt_gamma, g.dt_min, g.dt_max);
 
-    // cascade level = max(level of the position, level of the step size), clamped to [0, C-1]
-    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    int lp = frexp_exponent(mx);
-    int ld = frexp_exponent((float)((double)(dt * g.Hf) * 0.5));
-    lp = lp < 0 ? 0 : lp; ld = ld < 0 ? 0 : ld;
-    int level = lp > ld ? lp : ld;
-    level = level > g.C - 1 ? g.C - 1 : level;
-
-    const float mip_bound = fminf(scalbnf(1.0f, level), g.bound);
-    const float mip_rbound = 1.0f / mip_bound;
+    // cascade level = max(level of the position, level of the step size), clamped to [0, C-1]; with one cascade that
+    // is level 0 whatever the two exponents are
+    int level = 0;
+    float mip_bound = g.mip_bound0, mip_rbound = g.mip_rbound0;
+    if (!g.one_level) {
+        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        int lp = frexp_exponent(mx);
+        int ld = g.h_pow2 ? frexp_exponent(dt * g.half_H) : frexp_exponent((float)((double)(dt * g.Hf) * 0.5));
+        lp = lp < 0 ? 0 : lp; ld = ld < 0 ? 0 : ld;
+        level = lp > ld ? lp : ld;
+        level = level > g.C - 1 ? g.C - 1 : level;
+        mip_bound = fminf(scalbnf(1.0f, level), g.bound);
+        mip_rbound = 1.0f / mip_bound;
+    }
     const int nx = voxel_coord(x, mip_rbound, g);
     const int ny = voxel_coord(y, mip_rbound, g);
     const int nz = voxel_coord(z, mip_rbound, g);

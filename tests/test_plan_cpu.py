@@ -37,7 +37,9 @@ def test_encode_segments_tile_every_level_exactly_once_and_balance(lib, n, step)
             assert 0 <= l < 16 and 0 <= t0 < t1 <= tiles
             covered[l, t0:t1] += 1
             order.append((l, t0))
-    assert (covered == 1).all()                   # every (level, tile) belongs to exactly one XCD
+    # levels 0 and 1 (4096 + 12 167 entries = 130 KB) are served from LDS by a kernel of their own (csrc/hashgrid.hip
+    # k_grid_encode_planes_lds) and are not in the XCD plan; every other (level, tile) belongs to exactly one XCD
+    assert (covered[:2] == 0).all() and (covered[2:] == 1).all()
     assert order == sorted(order)                 # the XCDs walk the (level, tile) list in order: contiguous segments
     if n == 10_878_464 and step == STEP:
         # C2: the XCD that takes the cheap coarse levels takes several of them, the fine levels (3x the cost per tile) are
