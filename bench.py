@@ -565,8 +565,8 @@ def main():
             return ev * SCATTER_BYTES_PER_EVAL * (c["nonzero_pair_fraction"] if c else 1.0)
 
         roofs = [
-            roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, "
-                 "non-temporal plane stores; csrc/hashgrid.hip)", "encode", ENCODE_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS, "GB/s",
+            roof("k_grid_encode_planes (13-point hash-grid gather, levels tied to XCDs, 16-byte pair loads, non-temporal "
+                 "plane stores) + k_grid_encode_planes_lds (levels 0-1 from LDS, ~0.8 ms of it); csrc/hashgrid.hip", "encode", ENCODE_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS, "GB/s",
                  "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
                  "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
                  "k_grid_encode_planes"),

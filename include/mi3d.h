@@ -172,6 +172,13 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
                                    uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                                    void *out_planes, int out_half, void *stream);
+/* ... with a DEVICE-side sample count (count == NULL: all n): samples s >= *count are not evaluated, their rows are not
+ * written; the plane strides stay n.  Used by the inference loop, whose row count lives in its control block. */
+int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint32_t n, const int32_t *count,
+                                           const float *offsets_host, uint32_t P0, uint32_t P, float bound,
+                                           const float *params, uint32_t n_levels, uint32_t base_resolution,
+                                           float per_level_scale, uint32_t log2_hashmap_size, float step, void *out_planes,
+                                           int out_half, void *stream);
 int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const int32_t *count,
                              const float *offsets_host, uint32_t P0, uint32_t P, float bound, const float *dout,
                              uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
@@ -231,6 +238,13 @@ int mi3d_mlp_forward(const void *x, uint32_t x_plane_rows, int planes_half, uint
  * gradients (fp32, same layouts as the weights; caller zeroes them).  Activations are recomputed.
  * dx_plane_rows == 0: dx is [n, dim_in] rows; otherwise dx is level-major planes [dim_in/2][dx_plane_rows][2]
  * (feature pair (2l, 2l+1) of row r at dx[(l*dx_plane_rows + r)*2]), the layout mi3d_grid_scatter_binned consumes. */
+/* The same with a DEVICE-side row count (the inference loop's control block, Part 1b): rows are point-major with
+ * `n_stride` rows per stencil point, and only samples s < *count carry data; tiles wholly beyond it are skipped and
+ * their outputs left untouched.  count == NULL: every row.  (The gather and the head have the same variant.) */
+int mi3d_mlp_forward_counted(const void *x, uint32_t x_plane_rows, int planes_half, uint32_t n, const int32_t *count,
+                             uint32_t n_stride, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
+                             int half_mode, float *out, void *stream);
 int mi3d_mlp_backward(const void *x, uint32_t x_plane_rows, int planes_half, const float *dout, uint32_t n,
                       const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                       const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, int half_mode, void *dx,
@@ -249,6 +263,10 @@ int mi3d_mlp_backward(const void *x, uint32_t x_plane_rows, int planes_half, con
 int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon, float *sigma,
                             float *albedo, float *normal, float *normal2, void *stream);
+int mi3d_field_head_forward_counted(const float *h, const float *x, const float *x2, uint32_t n, const int32_t *count,
+                                    const float *offsets_host, uint32_t P, float bound, float blob_density,
+                                    float blob_radius, float epsilon, float *sigma, float *albedo, float *normal,
+                                    float *normal2, void *stream);
 /* Backward: upstream gradients (any may be NULL = zero) -> dh [P_active, n, 4], the rows of the first P_active
  * points only: 1 (sigma / albedo alone carry a gradient: the SDS pass), 7 (+ normal) or 13 (+ normal2); the caller
  * runs the MLP backward and the scatter over that prefix.  trunc_exp's clamped derivative (activation.py:15-18),

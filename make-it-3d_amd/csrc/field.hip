@@ -923,7 +923,8 @@ __device__ __forceinline__ void load_rows_raw_g(const float *__restrict__ x, siz
 template <class P, int NTH, int LAYERS, bool HP>
 __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_fwd_g(const float *__restrict__ x, uint32_t x_planes,
                                                                         uint32_t n, uint32_t din, Weights w,
-                                                                        float *__restrict__ out) {
+                                                                        float *__restrict__ out,
+                                                                        const int32_t *__restrict__ count, uint32_t n_stride) {
     using B = Blk<NTH, LAYERS>;
     using KB = typename P::KB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -944,7 +945,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_fwd_g(const float
         return bias_tile(biasT, tile, hh);
     };
     const uint32_t last_plane = din / 2 - 1;
+    // `count` (device, optional): rows are point-major, row = point * n_stride + sample, and only samples below *count
+    // carry data - a tile all of whose rows are beyond it is skipped (its outputs are never read)
+    const uint32_t c_rows = count ? (uint32_t)max(*count, 0) : 0xFFFFFFFFu;
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        if (count) {
+            const uint32_t s0 = (tile * 32u) % n_stride;
+            if (s0 >= c_rows && s0 + 32u <= n_stride) continue;
+        }
         const size_t row = (size_t)tile * 32 + p;
         KB X;
         if constexpr (HP) {
@@ -1273,9 +1281,10 @@ __device__ __forceinline__ void head_normal(const float s[6], float inv_2eps, fl
 }
 
 __global__ void k_head_forward(const float4 *__restrict__ h, HeadArgs a, uint32_t n, float *__restrict__ sigma,
-                               float *__restrict__ albedo, float *__restrict__ normal, float *__restrict__ normal2) {
+                               float *__restrict__ albedo, float *__restrict__ normal, float *__restrict__ normal2,
+                               const int32_t *__restrict__ count) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    if (s >= n || (count && (int32_t)s >= *count)) return;  // (device row count, optional: rows beyond it carry nothing)
     float bx[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
     const float4 h0 = h[s];  // rows are point-major: (sample s, point p) at p*n + s, coalesced across the wave
     sigma[s] = expf(h0.x + head_gauss(a, bx, 0));
@@ -1393,10 +1402,10 @@ bool dims_ok(uint32_t di, uint32_t dh, uint32_t dout, uint32_t layers) {
 
 template <class P, int NTH, int LAYERS, bool HP>
 void launch_fwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, uint32_t n, uint32_t din, const Weights &w,
-                float *out) {
+                float *out, const int32_t *count, uint32_t n_stride) {
     using B = Blk<NTH, LAYERS>;
     hipLaunchKernelGGL((k_mlp_fwd_g<P, NTH, LAYERS, HP>), grid, dim3(kWave * kWavesPerWG),
-                       lds_bytes_g<P>(B::FWD_COUNT, B::BIAS_TILES), st, x, x_planes, n, din, w, out);
+                       lds_bytes_g<P>(B::FWD_COUNT, B::BIAS_TILES), st, x, x_planes, n, din, w, out, count, n_stride);
 }
 template <class P, int NTH, int LAYERS, bool HP>
 void launch_bwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, const float *dout, uint32_t n, uint32_t din,
@@ -1425,6 +1434,15 @@ int mi3d_mlp_supported(uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out, u
 int mi3d_mlp_forward(const void *xv, uint32_t x_plane_rows, int planes_half, uint32_t n, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
                      int half_mode, float *out, void *stream) {
+    return mi3d_mlp_forward_counted(xv, x_plane_rows, planes_half, n, nullptr, n ? n : 1u, W1, b1, W2, b2, W3, b3, dim_in,
+                                    dim_hidden, dim_out, half_mode, out, stream);
+}
+
+int mi3d_mlp_forward_counted(const void *xv, uint32_t x_plane_rows, int planes_half, uint32_t n, const int32_t *count,
+                             uint32_t n_stride, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, uint32_t dim_in, uint32_t dim_hidden, uint32_t dim_out,
+                             int half_mode, float *out, void *stream) {
+    if (n_stride == 0) return (int)hipErrorInvalidValue;
     const uint32_t layers = (W2 == nullptr && b2 == nullptr) ? 2u : 3u;
     if (!dims_ok(dim_in, dim_hidden, dim_out, layers) || (x_plane_rows != 0 && x_plane_rows < n) ||
         (planes_half && (x_plane_rows == 0 || !half_mode)) || W1 == nullptr || b1 == nullptr || W3 == nullptr ||
@@ -1448,9 +1466,9 @@ int mi3d_mlp_forward(const void *xv, uint32_t x_plane_rows, int planes_half, uin
         return (int)hipGetLastError();
     }
 #endif
-    if (half_mode && planes_half) MI3D_MLP_DISPATCH(launch_fwd, F16, true, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
-    else if (half_mode) MI3D_MLP_DISPATCH(launch_fwd, F16, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
-    else MI3D_MLP_DISPATCH(launch_fwd, F32, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out);
+    if (half_mode && planes_half) MI3D_MLP_DISPATCH(launch_fwd, F16, true, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out, count, n_stride);
+    else if (half_mode) MI3D_MLP_DISPATCH(launch_fwd, F16, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out, count, n_stride);
+    else MI3D_MLP_DISPATCH(launch_fwd, F32, false, nth, layers, grid, st, x, x_plane_rows, n, dim_in, w, out, count, n_stride);
     return (int)hipGetLastError();
 }
 
@@ -1500,11 +1518,19 @@ int mi3d_mlp_backward(const void *xv, uint32_t x_plane_rows, int planes_half, co
 int mi3d_field_head_forward(const float *h, const float *x, const float *x2, uint32_t n, const float *offsets_host,
                             uint32_t P, float bound, float blob_density, float blob_radius, float epsilon, float *sigma,
                             float *albedo, float *normal, float *normal2, void *stream) {
+    return mi3d_field_head_forward_counted(h, x, x2, n, nullptr, offsets_host, P, bound, blob_density, blob_radius, epsilon,
+                                           sigma, albedo, normal, normal2, stream);
+}
+
+int mi3d_field_head_forward_counted(const float *h, const float *x, const float *x2, uint32_t n, const int32_t *count,
+                                    const float *offsets_host, uint32_t P, float bound, float blob_density,
+                                    float blob_radius, float epsilon, float *sigma, float *albedo, float *normal,
+                                    float *normal2, void *stream) {
     if ((P != 7 && P != 13) || (P == 13 && (x2 == nullptr || normal2 == nullptr))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     const HeadArgs a = make_head_args(x, x2, offsets_host, P, bound, blob_density, blob_radius, epsilon);
     hipLaunchKernelGGL(k_head_forward, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(h), a, n, sigma, albedo, normal, normal2);
+                       reinterpret_cast<const float4 *>(h), a, n, sigma, albedo, normal, normal2, count);
     return (int)hipGetLastError();
 }
 

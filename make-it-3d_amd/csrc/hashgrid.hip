@@ -215,11 +215,13 @@ template <bool PAIR, bool NT>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
                                                                        EncodePlan plan, float *__restrict__ planes,
-                                                                       int out_half) {
+                                                                       int out_half, const int32_t *__restrict__ count) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds;
     const size_t rows_total = (size_t)n * ps.P;
+    // `count` (device, optional): only samples below *count are evaluated; the plane strides stay the caller's n
+    const uint32_t n_eff = count ? ((uint32_t)max(*count, 0) < n ? (uint32_t)max(*count, 0) : n) : n;
     for (uint32_t sg = 0; sg < plan.n_seg[xcd]; ++sg) {
         const EncodeSeg seg = plan.seg[xcd][sg];
         const uint32_t l = seg.level;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         if (wg_in_xcd >= seg.wgs) continue;
         for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += seg.wgs * kWaves) {
             const uint32_t s = tile * kTile + lane;
-            if (s >= n) continue;
+            if (s >= n_eff) continue;
             float base[2][3];
             load_bases(ps, s, true, base);
             for (uint32_t p = 0; p < ps.P; ++p) {
@@ -268,8 +270,10 @@ template <bool NT>
 __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(PointSet ps, uint32_t n,
                                                                              const float2 *__restrict__ table, GridTable T,
                                                                              uint32_t n_lds_levels,
-                                                                             float *__restrict__ planes, int out_half) {
+                                                                             float *__restrict__ planes, int out_half,
+                                                                             const int32_t *__restrict__ count) {
     extern __shared__ float2 lds_tab[];
+    const uint32_t n_eff = count ? ((uint32_t)max(*count, 0) < n ? (uint32_t)max(*count, 0) : n) : n;
     const uint32_t total = T.level[n_lds_levels - 1].offset + T.level[n_lds_levels - 1].size;  // levels are contiguous from 0
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) lds_tab[i] = table[i];
     __syncthreads();
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(Poi
     const size_t rows_total = (size_t)n * ps.P;
     for (uint32_t tile = blockIdx.x * kLdsWaves + wave; tile < n_tiles; tile += gridDim.x * kLdsWaves) {
         const uint32_t s = tile * kTile + lane;
-        if (s >= n) continue;
+        if (s >= n_eff) continue;
         float base[2][3];
         load_bases(ps, s, true, base);
         for (uint32_t l = 0; l < n_lds_levels; ++l) {
@@ -1467,6 +1471,16 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
                                    uint32_t P, float bound, const float *params, uint32_t n_levels,
                                    uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                                    void *out_planes, int out_half, void *stream) {
+    return mi3d_grid_encode_points_planes_counted(x, x2, n, nullptr, offsets_host, P0, P, bound, params, n_levels,
+                                                  base_resolution, per_level_scale, log2_hashmap_size, step, out_planes,
+                                                  out_half, stream);
+}
+
+int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint32_t n, const int32_t *count,
+                                           const float *offsets_host, uint32_t P0, uint32_t P, float bound,
+                                           const float *params, uint32_t n_levels, uint32_t base_resolution,
+                                           float per_level_scale, uint32_t log2_hashmap_size, float step, void *out_planes,
+                                           int out_half, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
         (P0 < P && x2 == nullptr))
         return (int)hipErrorInvalidValue;
@@ -1504,18 +1518,18 @@ int mi3d_grid_encode_points_planes(const float *x, const float *x2, uint32_t n, 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         const uint32_t wgs = (tiles + kLdsWaves - 1) / kLdsWaves;
         hipLaunchKernelGGL((k_grid_encode_planes_lds<true>), dim3(wgs < 256u ? wgs : 256u), dim3(kWave * kLdsWaves), lds_bytes,
-                           st, ps, n, tab, T, n_lds, out, out_half);
+                           st, ps, n, tab, T, n_lds, out, out_half, count);
         if (n_lds == T.n_levels) return (int)hipGetLastError();
     }
     const EncodePlan plan = make_encode_plan(T, tiles, step01, only_level, wgs_coarse, wgs_fine, n_lds);
     const uint32_t per_xcd = wgs_coarse;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     if ((variant & 3) == 3)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
     else if (variant & 1)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
     else
-        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half);
+        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
     return (int)hipGetLastError();
 }
 

@@ -44,14 +44,17 @@ _SIGNATURES = {
     "mi3d_grid_scatter_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
     "mi3d_grid_encode_points_planes": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, i32, vp],
     "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, i32, u32, u32, f32, u32, f32, vp, C.c_size_t, vp, vp],
+    "mi3d_grid_encode_points_planes_counted": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, i32, vp],
     "mi3d_grid_encode_plan": [u32, f32, f32, u32, u32, f32, u32, vp, vp],           # host-side queries
     "mi3d_grid_scatter_plan": [u32, u32, f32, f32, u32, u32, f32, u32, C.c_size_t, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],
     "mi3d_mlp_forward": [vp, u32, i32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
+    "mi3d_mlp_forward_counted": [vp, u32, i32, u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],
     "mi3d_mlp_backward": [vp, u32, i32, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, u32, vp, vp, vp, vp, vp, vp, vp],
     # Part 5 ------------------------------------------------------------------------------------------
     "mi3d_field_head_forward": [vp, vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "mi3d_field_head_forward_counted": [vp, vp, vp, u32, vp, vp, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
     "mi3d_field_head_backward": [vp, vp, vp, u32, vp, u32, u32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
     # Part 6 ------------------------------------------------------------------------------------------
     "mi3d_sumsq_accumulate": [vp, C.c_size_t, vp, vp],

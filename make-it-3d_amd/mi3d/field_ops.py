@@ -76,23 +76,23 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
     return grad
 
 
-def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step=0.0):
+def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step=0.0, count=None):
     """feats [L][P*n][2] and h [P*n, 4] (point-major rows).  Under torch.autocast(float16) the planes hold binary16
     pairs: the first nn.Linear of the reference rounds its input to binary16 there, so the MLP output is bit-identical
     and every pass over the planes moves half the bytes."""
     P, n = offs.shape[0], x.shape[0]
     pdt = torch.float16 if half_mode else torch.float32
     feats = torch.empty(cfg["n_levels"], P * n, 2, dtype=pdt, device=x.device)
+    # `count`: an int32 device scalar (the inference loop's row count) - samples beyond it are skipped by every kernel
     grid_ops._timed("encode", lambda: L.call(
-        "mi3d_grid_encode_points_planes", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(params),
-        cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-        L.ptr(feats), int(bool(half_mode)), L.stream(x)), n * P)
+        "mi3d_grid_encode_points_planes_counted", L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, int(P0), P, float(bound),
+        L.ptr(params), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"],
+        float(step), L.ptr(feats), int(bool(half_mode)), L.stream(x)), n * P)
     dims = (ws[0].shape[1], ws[0].shape[0], ws[4].shape[0])
     h = torch.empty(P * n, dims[2], dtype=torch.float32, device=x.device)
     grid_ops._timed("mlp_fwd", lambda: L.call(
-        "mi3d_mlp_forward", L.ptr(feats), P * n, int(bool(half_mode)), P * n, *[L.ptr(t) for t in ws], *dims,
-        int(half_mode), L.ptr(h),
-        L.stream(x)), n * P)
+        "mi3d_mlp_forward_counted", L.ptr(feats), P * n, int(bool(half_mode)), P * n, L.ptr(count), max(n, 1),
+        *[L.ptr(t) for t in ws], *dims, int(half_mode), L.ptr(h), L.stream(x)), n * P)
     return feats, h, dims
 
 
@@ -163,16 +163,17 @@ def field_stencil(params, layers, x, offsets, cfg, bound=1.0, x2=None, P0=None, 
                                _half_mode(half_mode))
 
 
-def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon):
+def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon, count=None):
     P, n, dev = offs.shape[0], x.shape[0], x.device
-    sigma = torch.empty(n, dtype=torch.float32, device=dev)
-    albedo = torch.empty(n, 3, dtype=torch.float32, device=dev)
-    normal = torch.empty(n, 3, dtype=torch.float32, device=dev)
-    normal2 = torch.empty(n, 3, dtype=torch.float32, device=dev) if P == 13 else None
+    alloc = torch.empty if count is None else torch.zeros   # rows beyond a device count are not written: keep them defined
+    sigma = alloc(n, dtype=torch.float32, device=dev)
+    albedo = alloc(n, 3, dtype=torch.float32, device=dev)
+    normal = alloc(n, 3, dtype=torch.float32, device=dev)
+    normal2 = alloc(n, 3, dtype=torch.float32, device=dev) if P == 13 else None
     grid_ops._timed("head_fwd", lambda: L.call(
-        "mi3d_field_head_forward", L.ptr(h), L.ptr(x), L.ptr(x2), n, offs_p, P, float(bound), float(blob_density),
-        float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal), L.ptr(normal2),
-        L.stream(x)), n)
+        "mi3d_field_head_forward_counted", L.ptr(h), L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, P, float(bound),
+        float(blob_density), float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal),
+        L.ptr(normal2), L.stream(x)), n)
     return sigma, albedo, normal, normal2
 
 
@@ -287,6 +288,25 @@ class _Field(Function):
             gp, wg = _backward_mlp_scatter(dh, feats, ws, dims, x, x2 if has_x2 else None, offs, P0, bound, cfg, step,
                                            n_params, half_mode, P_active)
         return (gp, *wg, *none[:11])
+
+
+@torch.no_grad()
+def field_rows(params, layers, x, offsets, cfg, bound, blob_density, blob_radius, count, step=0.0, half_mode=None,
+               epsilon=grid_ops.EPS):
+    """Forward only (sigma, albedo, normal) of the 7-point stencil for the rows below the DEVICE-side `count` (int32[1]):
+    the inference loop's field call (renderer.py:546) - gather, MLP and head skip the rows the round does not use, so a
+    stale host-side upper bound of the row count costs launches of empty tiles, not field evaluations."""
+    x = L.dev_f32(x.contiguous().view(-1, 3).float(), "x", 3)
+    params = L.dev_f32(params.detach(), "params")
+    ws = mlp_ops._weights([None if t is None else t.detach() for t in mlp_ops.layer_args(layers)])
+    offs, offs_p = grid_ops._offs_arg(offsets)
+    if offs.shape[0] != 7:
+        raise L.Mi3dError("field_rows takes the 7-point stencil")
+    count = L.dev_typed(count, "count", torch.int32)
+    with L.on(x):
+        _, h, _ = _forward_encode_mlp(params, ws, x, None, offs, offs_p, 7, bound, cfg, _half_mode(half_mode), step, count)
+        sigma, albedo, normal, _ = _head_forward(h, x, None, offs, offs_p, bound, blob_density, blob_radius, epsilon, count)
+    return sigma, albedo, normal
 
 
 def field(params, layers, x, offsets, cfg, bound, blob_density, blob_radius, x2=None, P0=None, step=0.0,

@@ -174,6 +174,15 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d, l=None, ratio=1, shading="albedo"):
         """sigma [n], color [n,3], normal [n,3] (network_tcnn.py:140-170); 7 evaluations in one stencil pass."""
+        rows = getattr(self, "_infer_rows", None)
+        if (rows is not None and not torch.is_grad_enabled() and x.is_cuda and self.sigma_net.fused_ok(x)
+                and self.encoder.cfg["n_levels"] * 2 == self.sigma_net.dim_in):
+            # the inference loop (renderer.run_cuda, eval): the round's row count lives on the device
+            offs, _ = grid_ops.stencil_offsets(center=True, second=False)
+            sigma, albedo, normal = field_ops.field_rows(self.encoder.params, self.sigma_net.net, x.reshape(-1, 3), offs,
+                                                         self.encoder.cfg, float(self.bound), self.opt.blob_density,
+                                                         self.opt.blob_radius, rows)
+            return sigma, self.shade(albedo, normal, l, ratio, shading), normal
         sigma, albedo, normal, _ = self.field_stencil(x)
         return sigma, self.shade(albedo, normal, l, ratio, shading), normal
 

@@ -216,12 +216,14 @@ class NeRFRenderer(nn.Module):
             depth = torch.zeros(N, dtype=torch.float32, device=device)
             image = torch.zeros(N, 3, dtype=torch.float32, device=device)
             normal = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            # The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list - kept
-            # on the DEVICE (raymarching.*_ctl, C ABI Part 1b): every round is launched for an upper bound of the alive
-            # count and the real one is read back only every `sync_every` rounds, instead of one boolean-mask
+            # The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list, the row
+            # count - kept on the DEVICE (raymarching.*_ctl, C ABI Part 1b): every round is launched for an upper bound of
+            # the alive count, every kernel of the round - march, gather, MLP, head, composite, compaction - reads the true
+            # counts from the control block and skips what lies beyond them, and the host reads them back only every
+            # `sync_every` rounds (every round while the alive count is collapsing), instead of one boolean-mask
             # synchronisation per round.  Same arithmetic, same round structure, same results.
             rays_t = nears.clone()
-            align, sync_every = 128, 4
+            align, sync_every = 128, 8
             rows_cap = N + 2 * align
             xyzs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
             dirs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
@@ -236,8 +238,12 @@ class NeRFRenderer(nn.Module):
                 raymarching.march_rays_ctl(ctl, n_ub, alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
                                            self.cascade, self.grid_size, fars, xyzs, dirs, deltas, noises, dt_gamma,
                                            max_steps)
-                sigmas, rgbs, normals = self(xyzs[:rows_ub], dirs[:rows_ub], light_d, ratio=ambient_ratio,
-                                             shading=shading)
+                self._infer_rows = ctl[2:3]              # the round's true row count, on the device (field_ops.field_rows)
+                try:
+                    sigmas, rgbs, normals = self(xyzs[:rows_ub], dirs[:rows_ub], light_d, ratio=ambient_ratio,
+                                                 shading=shading)
+                finally:
+                    self._infer_rows = None
                 raymarching.composite_rays_ctl(ctl, n_ub, alive, rays_t, sigmas, rgbs, (normals + 1) / 2,
                                                deltas[:rows_ub], weights_sum, depth, image, normal, T_thresh)
                 raymarching.compact_alive_ctl(ctl, alive, spare, N, align, max_steps)

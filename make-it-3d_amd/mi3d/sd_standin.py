@@ -381,7 +381,8 @@ class StableDiffusionStandIn(nn.Module):
                         self.unet(gx, gt, encoder_hidden_states=gc)
                 torch.cuda.current_stream(x.device).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: a collective's watchdog thread (RCCL runs) may touch the device while this captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     gy = self.unet(gx, gt, encoder_hidden_states=gc)
                 self._graph = (key, g, gx, gt, gc, gy)
             except Exception:  # noqa: BLE001 - capture is an optimisation, never a requirement
