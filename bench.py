@@ -18,8 +18,9 @@ The HEADLINE (`value`, `ms_per_step`) is the like-for-like configuration: what t
 drop-in packages and NO edits to nerf/sd.py / nerf/utils.py - the reference's two-backward SDS schedule
 (`latents.backward(retain_graph=True)` then `scaler.scale(loss).backward()`) - and fp32 gradient contributions in the
 hash-grid scatter (tiny-cuda-nn adds fp32 products; the binary16-record mode of round 1 is gone: the 16-byte fp32
-pair records of round 2 are faster than it was).  `variants_ms_per_step` adds the hand-merged single-backward schedule
-(needs edits to nerf/sd.py), timed on its own steps.
+pair records of round 2 are faster than it was).  `variants_ms_per_step` adds two schedules that need edits to nerf/sd.py /
+nerf/utils.py, each timed on its own steps: the hand-merged single backward, and "overlapped" = the reference's two
+backward passes with the U-Net on a second HIP stream under the regulariser pass (mi3d/sds_step.py).
 
 The JSON line also carries
   roofline     : the step's dominant kernel - algorithmic bytes per launch (1024 B per field evaluation
@@ -518,6 +519,8 @@ def main():
     if args.variant_steps > 0 and not render_only:
         e, _, _ = run("fp32", "single", args.variant_steps, 1)
         variants["records=fp32,sds_backward=single"] = 1e3 * e / args.variant_steps
+        e, _, _ = run("fp32", "overlapped", args.variant_steps, 1)
+        variants["records=fp32,sds_backward=overlapped"] = 1e3 * e / args.variant_steps
 
     # ---- untimed: which gradient pairs one step's scatters actually carry, and the scatter on dense gradients
     census, dense = None, None

@@ -17,7 +17,10 @@
 // are summed in registers before they leave.
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/mi3d.h"
 #include "mi3d_dev.h"
@@ -40,10 +43,12 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // then mapped to [0,1] as (pt + bound) / (2 bound)  (network_tcnn.py:106,117-122).
 struct PointSet {
     const float *x, *x2;
-    float offs[kMaxPts * 3];
+    float4 offs[kMaxPts];  // one aligned 16-byte record per point: ONE scalar load in the point loops
     uint32_t P0, P;
     float bound;
     int mode;
+    float inv2b;  // 1 / (2 bound)
+    int pow2b;    // 2 bound is a power of two: t * inv2b IS t / (2 bound) (one real number, correctly rounded either way)
 };
 
 __device__ __forceinline__ void load_bases(const PointSet &ps, uint32_t s, bool valid, float (&b)[2][3]) {
@@ -53,17 +58,31 @@ __device__ __forceinline__ void load_bases(const PointSet &ps, uint32_t s, bool 
         b[1][d] = (valid && ps.x2 != nullptr) ? ps.x2[(size_t)s * 3 + d] : 0.f;
     }
 }
-__device__ __forceinline__ void point_of(const PointSet &ps, const float (&b)[2][3], uint32_t p, float (&q)[3]) {
-    const int which = p < ps.P0 ? 0 : 1;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (ps.mode == 0) {
-            q[d] = b[which][d];
-        } else {
-            const float w = clampf(b[which][d] + ps.offs[p * 3 + d], -ps.bound, ps.bound);
-            q[d] = (w + ps.bound) / (2.0f * ps.bound);
-        }
+__device__ __forceinline__ void point_of(const PointSet &ps, const float (&b)[2][3], uint32_t p, const float4 o,
+                                         float (&q)[3]) {
+    // (written so that the wave-uniform choices cost scalar instructions: one 16-byte scalar load for the offset - `o` is
+    // ps.offs[p], which a point loop fetches one iteration ahead - and one select per coordinate for the base; indexing
+    // b[which][d] made hipcc walk all six registers per coordinate)
+    const bool second = p >= ps.P0;
+    const float bx = second ? b[1][0] : b[0][0], by = second ? b[1][1] : b[0][1], bz = second ? b[1][2] : b[0][2];
+    if (ps.mode == 0) {
+        q[0] = bx; q[1] = by; q[2] = bz;
+        return;
     }
+    const float w[3] = {clampf(bx + o.x, -ps.bound, ps.bound), clampf(by + o.y, -ps.bound, ps.bound),
+                        clampf(bz + o.z, -ps.bound, ps.bound)};
+    // (the IEEE division is ~12 instructions per coordinate; the reference's bounds - 1, 2, ... - never need it)
+    if (ps.pow2b) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = (w[d] + ps.bound) * ps.inv2b;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = (w[d] + ps.bound) / (2.0f * ps.bound);
+    }
+}
+
+__device__ __forceinline__ void point_of(const PointSet &ps, const float (&b)[2][3], uint32_t p, float (&q)[3]) {
+    point_of(ps, b, p, ps.offs[p], q);
 }
 
 // Feature / gradient planes hold one pair per (level, row): fp32 (8 bytes) or - under torch.autocast(float16), where
@@ -211,18 +230,168 @@ __device__ __forceinline__ void gather_corners(const GridLevel &L, const float2 
     }
 }
 
+// Fast index paths.  grid_entry() is the general rule (any dims, any table size, any input): ~30 instructions and four
+// uniform branches per corner pair, and with them the gather's coarse levels were INSTRUCTION-bound - ~300 issued
+// instructions per (point, level) = the 0.84-1.05 ms those levels cost whether their table sat in the L1 or in LDS.
+// Two level shapes cover every level the reference's configurations build, and a stencil point (PointSet mode 1) is
+// clamped into [0, 1], so its cell coordinates never exceed res - 1:
+//   kDense3    3-D strided index, cy * res and cz * res^2 in 24-bit multiplies.  The index wraps (grid_entry's
+//              `index >= size`) only for the +1 corners of the box's last cells: ONE compare on the largest of the
+//              four (y, z) bases decides for all eight corners, and a wave with such a lane takes the general path for
+//              that point.  Everywhere else entries e and e + 1 are neighbours in memory: one 8-byte-aligned 16-byte
+//              load per (y, z) pair, no select.
+//   kHashPow2  power-of-two table: (cx ^ cy p1 ^ cz p2) & mask, the +1 bases by adding the prime; the x+1 corner is
+//              the other half of the aligned 16-byte slot exactly when cx is even (x enters with prime 1): ONE
+//              predicate for the four pairs, the odd lanes fetch their four x+1 corners behind the slots.
+// Same entries, same weights, same order of the eight fused multiply-adds: the planes are bit-identical.
+enum LevelKind : int { kGeneral = 0, kDense3 = 1, kHashPow2 = 2 };
+struct LevelFast {
+    int kind;
+    uint32_t res2;     // res * res (kDense3)
+    uint32_t last;     // size - 1: the mask (kHashPow2), the entry whose x+1 neighbour wraps (kDense3)
+};
+__host__ __device__ __forceinline__ LevelFast level_fast(const GridLevel &L, int mode) {
+    LevelFast f = {kGeneral, L.res * L.res, L.size - 1u};
+    if (mode == 0) return f;  // raw positions may lie outside [0, 1]
+    if (L.hashed) {
+        if ((L.size & (L.size - 1u)) == 0u && L.size >= 2u) f.kind = kHashPow2;
+    } else if (L.dims == 3 && L.res >= 2u && (uint64_t)L.res * L.res * L.res < (1ull << 31) &&
+               (uint64_t)L.res * L.res * L.res <= (uint64_t)L.size) {
+        f.kind = kDense3;  // the largest corner index, res (1 + res + res^2), is below 2 size: it wraps at most once
+    }
+    return f;
+}
+struct __attribute__((packed, aligned(8))) EntryPair { float ax, ay, bx, by; };  // entries e, e + 1 of a level
+
+// four corner entries of a cell - the z-bit `zb` half of its eight, corner j = x-bit | y-bit << 1 - by the short routes
+// (grid_entry's values)
+__device__ __forceinline__ void corner_entries4(const GridLevel &L, const LevelFast &F, uint32_t cx, uint32_t cy,
+                                                uint32_t cz, uint32_t zb, uint32_t (&e)[4]) {
+    if (F.kind == kHashPow2) {
+        const uint32_t hy = cy * kPrimeY, hz = (cz + zb) * kPrimeZ, a = hy ^ hz, b = (hy + kPrimeY) ^ hz, cx1 = cx + 1u;
+        e[0] = (a ^ cx) & F.last; e[1] = (a ^ cx1) & F.last; e[2] = (b ^ cx) & F.last; e[3] = (b ^ cx1) & F.last;
+        return;
+    }
+    if (F.kind == kDense3) {  // an index wraps at most once (level_fast): min(e, e - size) in unsigned arithmetic
+        const uint32_t a = cx + __umul24(cy, L.res) + __umul24(cz + zb, F.res2), b = a + L.res, size = F.last + 1u;
+        e[0] = min(a, a - size); e[1] = min(a + 1u, a + 1u - size); e[2] = min(b, b - size); e[3] = min(b + 1u, b + 1u - size);
+        return;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) e[j] = grid_entry(L, cx + (j & 1u), cy + (j >> 1), cz + zb);
+}
+
+// returns false if this wave has to take the general path for the point (kDense3: a lane in the box's last cells)
+template <int KIND, bool PAIR>
+__device__ __forceinline__ bool gather_corners_fast(const GridLevel &L, const LevelFast &F, const float2 *__restrict__ lvl,
+                                                    uint32_t cx, uint32_t cy, uint32_t cz, float2 (&v)[8]) {
+    if (KIND == kDense3) {
+        const uint32_t yz0 = __umul24(cy, L.res) + __umul24(cz, F.res2);
+        const uint32_t yz[4] = {yz0, yz0 + L.res, yz0 + F.res2, yz0 + L.res + F.res2};
+        if (__any(cx + yz[3] >= F.last)) return false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const EntryPair t = *reinterpret_cast<const EntryPair *>(lvl + (cx + yz[j]));
+            v[2 * j] = make_float2(t.ax, t.ay);
+            v[2 * j + 1] = make_float2(t.bx, t.by);
+        }
+        return true;
+    }
+    const uint32_t hy = cy * kPrimeY, hz = cz * kPrimeZ;
+    const uint32_t hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
+    const uint32_t yz[4] = {hy ^ hz, hy1 ^ hz, hy ^ hz1, hy1 ^ hz1};
+    if (!PAIR) {
+        const uint32_t cx1 = cx + 1u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            v[2 * j] = lvl[(yz[j] ^ cx) & F.last];
+            v[2 * j + 1] = lvl[(yz[j] ^ cx1) & F.last];
+        }
+        return true;
+    }
+    const bool cx_odd = cx & 1u;
+    const uint32_t cx1 = cx + 1u, slot_mask = F.last & ~1u;
+    float4 t[4];
+    float2 u[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t e0 = yz[j] ^ cx;
+        t[j] = *reinterpret_cast<const float4 *>(lvl + (e0 & slot_mask));
+        // the x+1 corner of an odd cx sits elsewhere in the level - 15 times out of 16 in the same 128-byte line; issued
+        // directly behind the slot it merges with the pending miss (see ORDER above)
+        if (cx_odd) u[j] = lvl[(yz[j] ^ cx1) & F.last];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const bool e0_odd = (yz[j] ^ cx) & 1u;
+        const float2 lo = make_float2(t[j].x, t[j].y), hi = make_float2(t[j].z, t[j].w);
+        v[2 * j] = e0_odd ? hi : lo;
+        v[2 * j + 1] = cx_odd ? u[j] : (e0_odd ? lo : hi);
+    }
+    return true;
+}
+
+// one (tile, level): the P points of the lane's sample -> plane pairs
+template <int KIND, bool PAIR, bool NT>
+__device__ __forceinline__ void encode_points(const PointSet &ps, const float (&base)[2][3], const GridLevel &L,
+                                              const LevelFast &F, const float2 *__restrict__ lvl,
+                                              float *__restrict__ planes, int out_half, size_t plane0, uint32_t n,
+                                              uint32_t s) {
+    float4 o_next = ps.offs[0];
+    for (uint32_t p = 0; p < ps.P; ++p) {
+        float q[3];
+        const float4 o = o_next;
+        o_next = ps.offs[p + 1 < ps.P ? p + 1 : p];  // (scalar load, a point ahead of its use)
+        point_of(ps, base, p, o, q);
+        uint32_t cx, cy, cz;
+        float fx, fy, fz;
+        grid_cell(q[0], L.scale, cx, fx);
+        grid_cell(q[1], L.scale, cy, fy);
+        grid_cell(q[2], L.scale, cz, fz);
+        float2 v[8];
+        if (KIND == kGeneral || !gather_corners_fast<KIND, PAIR>(L, F, lvl, cx, cy, cz, v))
+            gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
+        const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+        // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
+        const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+        const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
+        store_plane_pair<NT>(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
+    }
+}
+
+// next unclaimed tile of every plan segment; one slot per launch in flight (zeroed in-stream before the launch)
+constexpr uint32_t kPlanSlots = 64;
+__device__ uint32_t g_encode_next[kPlanSlots * kXcds * kMaxSegs];
+
+#ifdef MI3D_DEV
+// tools build only: when each XCD started, and when it finished each of its segments (100 MHz wall clock), so
+// tools/kbench.py can see how well make_encode_plan's cost model balances the XCDs
+__device__ unsigned long long mi3d_dbg_encode[kXcds * (1 + kMaxSegs)];
+#endif
+
 template <bool PAIR, bool NT>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
                                                                        EncodePlan plan, float *__restrict__ planes,
-                                                                       int out_half, const int32_t *__restrict__ count) {
+                                                                       int out_half, const int32_t *__restrict__ count,
+                                                                       uint32_t *__restrict__ next) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t xcd = blockIdx.x % kXcds, wg_in_xcd = blockIdx.x / kXcds;
     const size_t rows_total = (size_t)n * ps.P;
     // `count` (device, optional): only samples below *count are evaluated; the plane strides stay the caller's n
     const uint32_t n_eff = count ? ((uint32_t)max(*count, 0) < n ? (uint32_t)max(*count, 0) : n) : n;
+#ifdef MI3D_DEV
+    if (threadIdx.x == 0) atomicMin(&mi3d_dbg_encode[xcd * (1 + kMaxSegs)], (unsigned long long)wall_clock64());
+#endif
     for (uint32_t sg = 0; sg < plan.n_seg[xcd]; ++sg) {
+#ifdef MI3D_DEV
+        if (sg > 0 && threadIdx.x == 0)
+            atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + sg], (unsigned long long)wall_clock64());
+#endif
         const EncodeSeg seg = plan.seg[xcd][sg];
         const uint32_t l = seg.level;
         const GridLevel L = T.level[l];
@@ -232,32 +401,36 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         // L1 beyond 3 per CU - the surplus workgroups skip its segments (and, the segments being ordered coarse to fine,
         // retire once the coarse ones are done)
         if (wg_in_xcd >= seg.wgs) continue;
-        for (uint32_t tile = seg.tile0 + wg_in_xcd * kWaves + wave; tile < seg.tile1; tile += seg.wgs * kWaves) {
+        const LevelFast F = level_fast(L, ps.mode);
+        // Tiles are CLAIMED, not dealt (next[] = the segment's next unclaimed tile; one claim in flight while the wave
+        // works on the previous one).  Dealt statically (tile = first + k * stride) the waves of an XCD drifted apart -
+        // the CU's oldest-first issue arbitration lets the first-dispatched workgroups finish a segment milliseconds
+        // before the last-dispatched ones, they move on, and the XCD's 4 MB L2 then holds two or three levels' tables at
+        // once (tools/kbench.py encode_xcds: level 7 still being walked at 28 ms of a 29.6 ms launch).
+        uint32_t *ctr = next ? next + xcd * kMaxSegs + sg : nullptr;
+        const uint32_t stride = seg.wgs * kWaves;
+        auto claim = [&](uint32_t prev) __attribute__((always_inline)) {
+            if (!ctr) return prev + stride;
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(ctr, 1u);
+            return seg.tile0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        };
+        uint32_t tile = ctr ? claim(0u) : seg.tile0 + wg_in_xcd * kWaves + wave;
+        while (tile < seg.tile1) {
             const uint32_t s = tile * kTile + lane;
+            tile = claim(tile);
             if (s >= n_eff) continue;
             float base[2][3];
             load_bases(ps, s, true, base);
-            for (uint32_t p = 0; p < ps.P; ++p) {
-                float q[3];
-                point_of(ps, base, p, q);
-                uint32_t cx, cy, cz;
-                float fx, fy, fz;
-                grid_cell(q[0], L.scale, cx, fx);
-                grid_cell(q[1], L.scale, cy, fy);
-                grid_cell(q[2], L.scale, cz, fz);
-                float2 v[8];
-                gather_corners<PAIR>(L, lvl, cx, cy, cz, v);
-                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
-                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
-                const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
-                store_plane_pair<NT>(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
-            }
+            if (F.kind == kDense3) encode_points<kDense3, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
+            else if (F.kind == kHashPow2) encode_points<kHashPow2, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
+            else encode_points<kGeneral, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
         }
     }
+#ifdef MI3D_DEV
+    if (threadIdx.x == 0)
+        atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + plan.n_seg[xcd]], (unsigned long long)wall_clock64());
+#endif
 }
 
 // The coarsest levels from LDS.  Levels whose tables fit a CU's LDS together (the default grid: level 0 = 4096 entries,
@@ -290,26 +463,10 @@ __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(Poi
             const GridLevel L = T.level[l];
             const float2 *lvl = lds_tab + L.offset;
             const size_t plane0 = (size_t)l * rows_total;
-            for (uint32_t p = 0; p < ps.P; ++p) {
-                float q[3];
-                point_of(ps, base, p, q);
-                uint32_t cx, cy, cz;
-                float fx, fy, fz;
-                grid_cell(q[0], L.scale, cx, fx);
-                grid_cell(q[1], L.scale, cy, fy);
-                grid_cell(q[2], L.scale, cz, fz);
-                float2 v[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) v[k] = lvl[grid_entry(L, cx + (k & 1u), cy + ((k >> 1) & 1u), cz + (k >> 2))];
-                const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order
-                const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
-                const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
-                float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
-                store_plane_pair<NT>(planes, out_half, plane0 + (size_t)p * n + s, r0, r1);
-            }
+            const LevelFast F = level_fast(L, ps.mode);
+            if (F.kind == kDense3) encode_points<kDense3, false, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
+            else if (F.kind == kHashPow2) encode_points<kHashPow2, false, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
+            else encode_points<kGeneral, false, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
         }
     }
 }
@@ -317,10 +474,12 @@ __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(Poi
 // Relative cost of one tile of a level, as a function of x = (marching step) x (level scale) = how many cells of the
 // level two consecutive samples of a ray are apart: the measured per-level times above, tabulated against x (C2: step
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
-inline double encode_level_cost(double x) {
-    // round 3 (profiles/kbench_r03_encode_wgs.json): ms per level at C2 with 6 workgroups per CU up to x = 0.26 and 3 beyond
+inline double encode_level_cost(double x, bool dense_fast) {
+    // round 3, after the short index routes (profiles/kbench_r03_encode_fast.json): ms per level at C2 with 6 workgroups
+    // per CU up to x = 0.26 and 3 beyond.  A dense level on the short route is instruction-bound and flat.
+    if (dense_fast) return 0.44;
     static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
-    static const double cs[] = {0.84, 0.85, 0.91, 1.00, 1.22, 1.53, 1.90, 2.60, 2.95, 3.08, 3.12, 3.15};
+    static const double cs[] = {0.74, 0.76, 0.84, 0.94, 1.10, 1.50, 1.98, 2.55, 2.87, 3.03, 3.06, 3.08};
     constexpr int N = sizeof(xs) / sizeof(xs[0]);
     if (x <= xs[0]) return cs[0];
     for (int i = 1; i < N; ++i)
@@ -333,11 +492,13 @@ inline uint32_t encode_level_wgs_per_cu(double x, uint32_t coarse, uint32_t fine
 
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
 inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level,
-                                   uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd, uint32_t first_level = 0) {
+                                   uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd, uint32_t first_level = 0,
+                                   int point_mode = 1) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
-        cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale);
+        cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale,
+                                    level_fast(T.level[l], point_mode).kind == kDense3);
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
         if (l < first_level) cost[l] = 0.0;  // served from LDS by k_grid_encode_planes_lds
         total += cost[l];
@@ -567,7 +728,15 @@ PointSet make_points(const float *x, const float *x2, const float *offsets_host,
                      int mode) {
     PointSet ps;
     ps.x = x; ps.x2 = x2; ps.P0 = P0; ps.P = P; ps.bound = bound; ps.mode = mode;
-    for (uint32_t i = 0; i < kMaxPts * 3; ++i) ps.offs[i] = (offsets_host && i < P * 3) ? offsets_host[i] : 0.f;
+    int ex = 0;
+    const float two_b = 2.0f * bound;
+    ps.pow2b = (two_b > 0.f && two_b >= 1.17549435e-38f && two_b <= 8.5e37f && frexpf(two_b, &ex) == 0.5f) ? 1 : 0;
+    ps.inv2b = ps.pow2b ? 1.0f / two_b : 0.f;
+    for (uint32_t i = 0; i < (uint32_t)kMaxPts; ++i) {
+        const bool have = offsets_host != nullptr && i < P;
+        ps.offs[i] = make_float4(have ? offsets_host[3 * i] : 0.f, have ? offsets_host[3 * i + 1] : 0.f,
+                                 have ? offsets_host[3 * i + 2] : 0.f, 0.f);
+    }
     return ps;
 }
 
@@ -877,6 +1046,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
             float lmax = 0.f;
             // wave-uniform, hoisted out of the point loop: the level's region capacity, this wave's counters and regions
             const uint32_t cap = plan.level_cap[l];
+            const LevelFast LF = level_fast(L, ps.mode);
             uint32_t *fill_l = fill + plan.level_bin0[l];
             RowRecord *region0 = reinterpret_cast<RowRecord *>(reinterpret_cast<char *>(arena) + plan.level_base[l]) +
                                  (size_t)gw * level_bins(L) * cap;
@@ -951,12 +1121,9 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
 #pragma unroll
                 for (uint32_t half = 0; half < 2; ++half) {  // two batches of four probes in flight (registers)
                     uint32_t e[4], slot[4], old[4];
+                    corner_entries4(L, LF, ex, ey, ez, half, e);
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) {
-                        const uint32_t k = 4 * half + j;
-                        e[j] = grid_entry(L, ex + (k & 1u), ey + ((k >> 1) & 1u), ez + (k >> 2));
-                        slot[j] = (e[j] * 2654435761u) >> (32 - 9);
-                    }
+                    for (uint32_t j = 0; j < 4; ++j) slot[j] = (e[j] * 2654435761u) >> (32 - 9);
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j) {
                         const uint32_t k = 4 * half + j;
@@ -1163,7 +1330,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                                 qb[dd] = base[which][dd];
                             } else {
                                 const float w = clampf(base[which][dd], -ps.bound, ps.bound);
-                                qb[dd] = (w + ps.bound) / (2.0f * ps.bound);
+                                qb[dd] = ps.pow2b ? (w + ps.bound) * ps.inv2b : (w + ps.bound) / (2.0f * ps.bound);
                             }
                         }
                         float unused;
@@ -1524,12 +1691,22 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     const EncodePlan plan = make_encode_plan(T, tiles, step01, only_level, wgs_coarse, wgs_fine, n_lds);
     const uint32_t per_xcd = wgs_coarse;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
+    uint32_t *next = nullptr;
+    if (MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0) {
+        static std::atomic<uint32_t> launches{0};
+        uint32_t *base = nullptr;
+        hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_encode_next));
+        if (e != hipSuccess) return (int)e;
+        next = base + (size_t)(launches.fetch_add(1u) % kPlanSlots) * kXcds * kMaxSegs;
+        e = hipMemsetAsync(next, 0, sizeof(uint32_t) * kXcds * kMaxSegs, st);
+        if (e != hipSuccess) return (int)e;
+    }
     if ((variant & 3) == 3)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
+        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
     else if (variant & 1)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
+        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
     else
-        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count);
+        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
     return (int)hipGetLastError();
 }
 
@@ -1700,3 +1877,20 @@ int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint
 
 
 }  // extern "C"
+
+#ifdef MI3D_DEV
+// tools build only: reset (reset != 0) or read the per-XCD timestamps of the last plane gather, and its plan
+extern "C" int mi3d_dev_encode_times(unsigned long long *out /* [8 * 17] */, int reset) {
+    unsigned long long h[kXcds * (1 + kMaxSegs)];
+    if (reset) {
+        for (uint32_t x = 0; x < kXcds; ++x) {
+            h[x * (1 + kMaxSegs)] = ~0ull;
+            for (int i = 1; i <= kMaxSegs; ++i) h[x * (1 + kMaxSegs) + i] = 0ull;
+        }
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi3d_dbg_encode), h, sizeof(h));
+    }
+    const int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(mi3d_dbg_encode), sizeof(h));
+    for (uint32_t i = 0; i < kXcds * (1 + kMaxSegs); ++i) out[i] = h[i];
+    return rc;
+}
+#endif

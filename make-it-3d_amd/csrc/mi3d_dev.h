@@ -29,6 +29,7 @@ enum : int {
     MI3D_T_ENCODE_COARSE_WGS_PER_CU = 12,
     MI3D_T_MARCH_RPW_MIN = 13,
     MI3D_T_MARCH_WAVES = 14,
+    MI3D_T_ENCODE_STATIC_TILES = 17,  // gather: 1 = tiles dealt statically (round 2's order) instead of claimed
     MI3D_T_ENCODE_LDS_LEVELS = 16,  // gather: levels served from LDS (default: as many as fit)
     MI3D_T_MERGE_STEPS_X10 = 15,   // scatter: a level is gathered per tile if its cells are >= this / 10 marching steps        // 1: the fine emit role walks level-major (one level's regions open at a time)
 };

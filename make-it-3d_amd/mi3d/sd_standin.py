@@ -345,8 +345,8 @@ class StableDiffusionStandIn(nn.Module):
         zt = zt / zt.norm(dim=-1, keepdim=True)
         return -(z1 * zt).sum(-1).mean()
 
-    def _predict_noise(self, text_embeddings, pred_rgb, guidance_scale, t):
-        """sd.py:124-151: 512 x 512 resize, VAE encode (with graph), noise, U-Net on the CFG pair, guidance."""
+    def _encode_view(self, pred_rgb, t):
+        """sd.py:124-136: 512 x 512 resize, timestep, VAE encode (with graph), the noise draw."""
         pred_rgb_512 = F.interpolate(pred_rgb, (512, 512), mode="bilinear", align_corners=False)
         # the branch rule (sd.py:153) needs t on the host; the reference draws it on the device and pays a sync in the
         # `if` - drawn on the host here (or passed in as an int) there is none
@@ -357,13 +357,59 @@ class StableDiffusionStandIn(nn.Module):
         latents = self.encode_imgs(pred_rgb_512)
         with torch.no_grad():
             noise = torch.randn_like(latents)
+        return latents, noise, t, t_host
+
+    def _guided_eps(self, text_embeddings, latents, noise, t, guidance_scale):
+        """sd.py:138-151 (no grad): add noise, U-Net on the CFG pair, guidance."""
+        with torch.no_grad():
             a = self.alphas[t].view(-1, 1, 1, 1)
             noisy = a.sqrt() * latents + (1 - a).sqrt() * noise
             eps = self._unet_forward(torch.cat([noisy] * 2).to(self.unet.conv_in.weight.dtype), t,
                                      text_embeddings.to(self.unet.conv_in.weight.dtype)).float()
             eps_uncond, eps_text = eps.chunk(2)
             eps = eps_text + guidance_scale * (eps_text - eps_uncond)  # sic: anchored on eps_text (sd.py:151)
+        return noisy, eps
+
+    def _predict_noise(self, text_embeddings, pred_rgb, guidance_scale, t):
+        """sd.py:124-151: 512 x 512 resize, VAE encode (with graph), noise, U-Net on the CFG pair, guidance."""
+        latents, noise, t, t_host = self._encode_view(pred_rgb, t)
+        noisy, eps = self._guided_eps(text_embeddings, latents, noise, t, guidance_scale)
         return latents, noise, noisy, eps, t, t_host
+
+    def sds_gradient_async(self, text_embeddings, pred_rgb, guidance_scale=10, t=None):
+        """The SDS branch with the U-Net on a second HIP stream: returns (latents with graph, finish).  The VAE encode
+        and every random draw stay on the calling stream in the reference's order (sd.py:124-136); the no-grad half
+        (sd.py:138-151,163-170) is queued on the side stream behind an event, so whatever the caller launches next on
+        its own stream - the regulariser backward pass in mi3d/sds_step.py - runs beside it.  `finish()` makes the
+        calling stream wait for the side stream and returns the SDS gradient [1,4,64,64]."""
+        from . import grid_ops
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+        latents, noise, t, _ = self._encode_view(pred_rgb, t)
+        lat = latents.detach()
+        ready = main.record_event()
+        for v in (lat, noise, t):
+            v.record_stream(side)   # allocated on the calling stream, read on the side stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            box = []
+
+            def unet_half():
+                _, eps = self._guided_eps(text_embeddings, lat, noise, t, guidance_scale)
+                with torch.no_grad():
+                    box.append(torch.nan_to_num((1 - self.alphas[t]) * (eps - noise)))
+            grid_ops._timed("sd_unet_side_stream", unet_half, 1)   # (events on the side stream)
+            grad = box[0]
+            done = side.record_event()
+
+        def finish():
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            grad.record_stream(cur)     # allocated on the side stream, consumed (and freed) on the caller's
+            return grad
+        return latents, finish
 
     def _unet_forward(self, x, t, ctx):
         """U-Net noise prediction; on the GPU through a captured hipGraph (torch.cuda.CUDAGraph) keyed on the shapes

@@ -13,6 +13,11 @@ tests, minus the CLIP terms (openai `clip` weights are unavailable offline and o
   "single"   : one backward of  scale*loss + <latents, grad.detach()> .  The parameter gradients are the same sum
                (the SDS term bypasses the loss scale in both, quirk SURVEY 9.10); the NeRF graph is walked once.
                (tests/test_sds_step_gpu.py checks the two agree.)
+  "overlapped": the reference's two backward passes with the U-Net off the critical path: the no-grad U-Net half of
+               guidance.train_step is queued on a second HIP stream, the regulariser backward pass (which needs nothing
+               from the diffusion model) runs beside it, then `latents.backward(grad)`.  Every parameter gradient is
+               the sum of the same two terms as in "reference", added in the other order (a + b == b + a in floating
+               point), every random draw happens in the same order on the same stream.
 """
 import math
 import types
@@ -74,6 +79,9 @@ def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, d
             if sds_backward == "reference":
                 guidance.train_step(text_z, pred_rgb, guidance_scale=opt.guidance_scale, t=t)  # NeRF backward #1
                 sds_term = None
+            elif sds_backward == "overlapped":
+                latents, finish_guidance = guidance.sds_gradient_async(text_z, pred_rgb, opt.guidance_scale, t)
+                sds_term = None
             else:
                 latents, grad = guidance.sds_gradient(text_z, pred_rgb, opt.guidance_scale, t)
                 sds_term = (latents.float() * grad.float()).sum()
@@ -83,7 +91,10 @@ def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, d
         total = scaler.scale(loss)
         if sds_term is not None:
             total = total + sds_term  # the SDS gradient is never loss-scaled (sd.py:171)
-        total.backward()
+        total.backward(retain_graph=sds_backward == "overlapped")
+    if sds_backward == "overlapped":
+        with phase("guidance_train_step"):
+            latents.backward(gradient=finish_guidance())   # sd.py:171, after the pass it no longer has to wait for
     with phase("sync_clip_optimizer"):
         if grad_sync is not None:
             grad_sync()

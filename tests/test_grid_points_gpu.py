@@ -255,3 +255,39 @@ def test_fused_field_node_runs_only_the_reached_stencil_prefix(cuda, oracle, rea
         scale = float(b.abs().max()) + 1e-12
         # MLP parameter gradients (i >= 5) are float-atomic sums over 39 000 rows of O(1) terms: run-to-run noise ~1e-4
         assert float((a - b).abs().max()) <= (2e-4 if i >= 5 else 2e-5) * scale, i
+
+
+@pytest.mark.parametrize("bound", [1.0, 2.0, 1.5])
+@pytest.mark.parametrize("levels,base,log2", [(16, 16, 19), (4, 16, 19), (6, 8, 12)])
+def test_plane_kernels_are_bit_identical_to_the_row_kernel(cuda, oracle, bound, levels, base, log2):
+    """The plane gather takes short index routes (dense levels: strided index, one 16-byte load per x-pair, served from LDS
+    where the tables fit; power-of-two hashed levels: mask, one predicate for the four pairs; power-of-two 2 * bound: a
+    multiplication for the division) - the row kernel takes grid_entry()'s general one.  Same cells, same entries, same
+    order of operations: equal to the bit, also on the box faces and in its far corner, where the +1 corners of a dense
+    level wrap (bound 1.5: the division path)."""
+    from mi3d import _lib as L, grid_ops
+    rng = np.random.default_rng(17)
+    cfg = oracle.GridConfig(bound=bound, n_levels=levels, base_resolution=base, log2_hashmap_size=log2)
+    kcfg = dict(n_levels=levels, base_resolution=base, per_level_scale=cfg.per_level_scale, log2_hashmap_size=log2)
+    n = 4096 + 37
+    x = _ray_like_points(rng, n, bound)
+    x[:64] = bound                                                     # the far corner: every +1 corner wraps
+    x[64:128] = np.where(rng.random((64, 3)) < 0.5, bound, x[64:128])   # faces and edges
+    x[128:160] = -bound
+    x[160:224] = bound * (1 - rng.random((64, 3)).astype(np.float32) * np.float32(0.02))   # the last cells
+    x2 = (x + rng.normal(size=x.shape).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    P = offs.shape[0]
+    params = T(rng.uniform(-1, 1, cfg.n_params).astype(np.float32), cuda)
+    xd, x2d = T(x, cuda), T(x2, cuda)
+    rows = grid_ops.encode_points(params, xd, offs, kcfg, bound, x2d, P0)          # [P n, 2 L], general index route
+    _, offs_p = grid_ops._offs_arg(offs)
+    for half in (0, 1):
+        planes = torch.full((levels, P * n, 2), 7.0, device=cuda, dtype=torch.float16 if half else torch.float32)
+        with L.on(xd):
+            L.call("mi3d_grid_encode_points_planes", L.ptr(xd), L.ptr(x2d), n, offs_p, int(P0), P, float(bound),
+                   L.ptr(params), levels, base, cfg.per_level_scale, log2, 2 * 3 ** 0.5 / 1024 * bound, L.ptr(planes),
+                   half, L.stream(xd))
+        got = planes.permute(1, 0, 2).reshape(P * n, 2 * levels)
+        want = rows.half() if half else rows
+        assert torch.equal(got, want), (half, float((got.float() - want.float()).abs().max()))

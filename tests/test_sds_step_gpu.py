@@ -93,6 +93,41 @@ def test_single_backward_equals_reference_two_backward(cuda):
         assert float((a - b).abs().max()) <= 1e-3 * scale, n
 
 
+def test_overlapped_schedule_equals_reference_two_backward(cuda):
+    """The U-Net on a second HIP stream under the regulariser pass, the SDS pass after it: the same two gradient terms
+    as the reference's order, summed the other way round (commutative) - equal up to the float-atomic noise of the MLP
+    weight gradients, with the regularisers that do not depend on row order switched on."""
+    off = dict(lambda_smooth=0.0, lambda_orient=0.0)
+    ovl, ref = _captured_grads(cuda, "overlapped", **off), _captured_grads(cuda, "reference", **off)
+    ref2 = _captured_grads(cuda, "reference", **off)
+    for n in ovl:
+        a, b = ovl[n], ref[n]
+        assert torch.isfinite(a).all()
+        scale = float(b.abs().max()) + 1e-12
+        noise = float((ref2[n] - b).abs().max())
+        assert float((a - b).abs().max()) <= 4 * noise + 1e-5 * scale, (n, noise, scale)
+    # the real (graph-captured) stand-in path too: one fp16 step per schedule from the same seed, same parameters after
+    from mi3d import sds_step
+    outs = []
+    for mode in ("reference", "overlapped"):
+        opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=True)
+        opt.lambda_smooth = model.opt.lambda_smooth = 0.0
+        opt.lambda_orient = model.opt.lambda_orient = 0.0
+        guidance = _TinyGuidance(cuda, deterministic=False)
+        guidance.impl.graph_unet = True
+        text_z = torch.randn(2, 77, 64, generator=torch.Generator().manual_seed(1)).to(cuda)
+        torch.manual_seed(7)
+        for _ in range(3):
+            sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt,
+                                    sds_backward=mode, t=500)
+        torch.cuda.synchronize()
+        outs.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in outs[0]:
+        a, b = outs[0][n], outs[1][n]
+        assert torch.isfinite(b).all()
+        assert float((a - b).norm()) <= 1e-3 * (float(a.norm()) + 1e-12), n   # (Adan normalises: compare in L2)
+
+
 def test_single_backward_with_regularisers_within_run_to_run_noise(cuda):
     """All regularisers on: the two schedules differ by no more than the same schedule differs from itself when
     repeated (row order -> jitter assignment, and float-atomic summation order; the reference has both properties)."""

@@ -92,6 +92,38 @@ def main():
         tune(T_ENCODE_WGS, -1)
     if "encode1" in what:  # the product configuration of the gather, once
         res["encode_ms"] = timeit(encode, 5)
+        it = torch.int16 if feats.dtype == torch.float16 else torch.int32   # bit-level checksum per level (A/B across builds)
+        res["encode_checksum"] = [int(feats[l].view(it).to(torch.int64).sum()) for l in range(feats.shape[0])]
+    if "encode_sweep" in what:  # workgroups per CU for the coarse / fine segments, tiles claimed
+        out = {}
+        for c in (4, 6, 7):
+            for f in (2, 3, 4, 5):
+                if f > c:
+                    continue
+                tune(12, c)
+                tune(T_ENCODE_WGS, f)
+                out[f"coarse{c}_fine{f}"] = timeit(encode, 3)
+        tune(12, -1)
+        tune(T_ENCODE_WGS, -1)
+        res["encode_ms_by_wgs_per_cu"] = out
+    if "encode_xcds" in what:  # when each XCD finished each of its plan segments (dev build's timestamps, 100 MHz)
+        import ctypes as C2
+        buf = (C2.c_ulonglong * (8 * 17))()
+        per = []
+        for lds, static in ((-1, 0), (0, 0)):
+            tune(16, lds)
+            tune(17, static)
+            ms = timeit(encode, 3)
+            lib.mi3d_dev_encode_times(buf, 1)
+            encode()
+            torch.cuda.synchronize()
+            lib.mi3d_dev_encode_times(buf, 0)
+            t0 = min(buf[x * 17] for x in range(8))
+            per.append({"lds_levels": lds, "static_tiles": static, "encode_ms": ms, "xcd_end_ms": [
+                max(round((buf[x * 17 + i] - t0) / 1e5, 3) for i in range(1, 17)) for x in range(8)]})
+        tune(17, -1)
+        tune(16, -1)
+        res["encode_xcd_timeline"] = per
     if "levels" in what:
         for v in (3,):
             tune(T_ENCODE_VARIANT, v)
@@ -151,9 +183,13 @@ def main():
         del dplanes, dh, h
     if "scatter13" in what:  # the 13-point scatter alone, as configured (--dev): for rocprofv3 --kernel-trace --stats
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        torch.manual_seed(11)
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
         res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240), a.iters)
-        del g
+        out = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240)
+        res["scatter_fp32_P13_checksum"] = int(out.view(torch.int32).to(torch.int64).sum())   # (A/B across builds)
+        del g, out
     if "scatter_levels" in what:  # the 13-point scatter per role and per level (dev level mask), dense random gradients
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
         masks = {"all": 0xFFFF, "fine_8_15": 0xFF00, "coarse_0_7": 0x00FF}
