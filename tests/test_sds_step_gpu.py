@@ -7,10 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, seed=0, fp16=True):
+def _setup(dev, seed=0, fp16=True, init_scale=None):
     from mi3d import rays as R, sd_standin, sds_step
     opt = sds_step.make_opt(max_steps=64, fp16=fp16)
-    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=seed, bitfield=0.5)
+    model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=seed, bitfield=0.5, init_scale=init_scale)
     with torch.no_grad():
         model.encoder.params.uniform_(-0.1, 0.1)
     ro, rd, ds = R.view_rays(32, 32, device=dev)
@@ -57,9 +57,9 @@ class _TinyGuidance(torch.nn.Module):
         return getattr(self.impl, k)
 
 
-def _captured_grads(cuda, mode, **opt_over):
+def _captured_grads(cuda, mode, fp16=False, **opt_over):
     from mi3d import sds_step
-    opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=False)
+    opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=fp16, init_scale=8.0 if fp16 else None)
     for k, v in opt_over.items():
         setattr(opt, k, v)
         setattr(model.opt, k, v)
@@ -106,26 +106,14 @@ def test_overlapped_schedule_equals_reference_two_backward(cuda):
         scale = float(b.abs().max()) + 1e-12
         noise = float((ref2[n] - b).abs().max())
         assert float((a - b).abs().max()) <= 4 * noise + 1e-5 * scale, (n, noise, scale)
-    # the real (graph-captured) stand-in path too: one fp16 step per schedule from the same seed, same parameters after
-    from mi3d import sds_step
-    outs = []
-    for mode in ("reference", "overlapped"):
-        opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=True)
-        opt.lambda_smooth = model.opt.lambda_smooth = 0.0
-        opt.lambda_orient = model.opt.lambda_orient = 0.0
-        guidance = _TinyGuidance(cuda, deterministic=False)
-        guidance.impl.graph_unet = True
-        text_z = torch.randn(2, 77, 64, generator=torch.Generator().manual_seed(1)).to(cuda)
-        torch.manual_seed(7)
-        for _ in range(3):
-            sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt,
-                                    sds_backward=mode, t=500)
-        torch.cuda.synchronize()
-        outs.append({n: p.detach().clone() for n, p in model.named_parameters()})
-    for n in outs[0]:
-        a, b = outs[0][n], outs[1][n]
-        assert torch.isfinite(b).all()
-        assert float((a - b).norm()) <= 1e-3 * (float(a.norm()) + 1e-12), n   # (Adan normalises: compare in L2)
+    # under autocast too (binary16 planes, loss scale 8): the same gradients within the run-to-run noise of the schedule
+    ovl, ref, ref2 = (_captured_grads(cuda, m, fp16=True, **off) for m in ("overlapped", "reference", "reference"))
+    for n in ovl:
+        a, b = ovl[n], ref[n]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), n
+        scale = float(b.abs().max()) + 1e-12
+        noise = float((ref2[n] - b).abs().max())
+        assert float((a - b).abs().max()) <= 4 * noise + 1e-4 * scale, (n, noise, scale)
 
 
 def test_single_backward_with_regularisers_within_run_to_run_noise(cuda):

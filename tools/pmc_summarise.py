@@ -16,7 +16,7 @@ import os
 import sys
 
 FAMILIES = [   # (family key, substring of the kernel name); round 3's generic MLP kernels keep the family names
-    ("k_grid_encode_planes", "k_grid_encode_planes"), ("k_mlp_forward", "k_mlp_forward"), ("k_mlp_forward", "k_mlp_fwd_g"),
+    ("k_grid_encode_planes_lds", "k_grid_encode_planes_lds"), ("k_grid_encode_planes", "k_grid_encode_planes"), ("k_mlp_forward", "k_mlp_forward"), ("k_mlp_forward", "k_mlp_fwd_g"),
     ("k_mlp_backward", "k_mlp_backward"), ("k_mlp_backward", "k_mlp_bwd_g"),
     ("k_bin_emit16", "k_bin_emit16"), ("k_bin_emit", "k_bin_emit("), ("k_bin_reduce", "k_bin_reduce"),
     ("k_head_forward", "k_head_forward"), ("k_head_backward", "k_head_backward"), ("k_march_train", "k_march_train"),
