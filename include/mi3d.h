@@ -161,7 +161,9 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
 /* mi3d_grid_encode_points with level-major output planes [n_levels][P*n][2] (feature pair of level l, row r = p*n + i
  * at out_planes[(l*P*n + r)*2]) - the layout the MLP kernels take with x_plane_rows = P*n.  The (level, tile) work is
  * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from; `step` (the marching
- * step in world units, 0 = unknown) only balances that split, never the result.
+ * step in world units, 0 = unknown) only balances that split, never the result.  The workgroups of an XCD claim their
+ * tiles from per-segment counters: 512 bytes of a 64-slot ring in device memory that belongs to the library, zeroed
+ * in `stream` before the launch - up to 64 of these calls may be in flight per device, on any streams.
  * PLANE ELEMENT TYPE: out_half == 0: fp32 pairs (8 bytes per (level, row)); out_half != 0: binary16 pairs (4 bytes) -
  * for use under torch.autocast(float16) only, where the first nn.Linear rounds its input to binary16 anyway
  * (mi3d_mlp_forward / _backward with half_mode != 0 read them with planes_half != 0: same MLP output, bit for bit,
