@@ -166,6 +166,10 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 // Output is level-major planes [L][P*n][2], row = p*n + s (point-major): the 64 lanes of a wave store 512 contiguous
 // bytes per point, and the MLP kernels read them with x_plane_rows = P*n.
 //
+// Round 3 corrected two things this comment used to get wrong: the coarse levels were instruction-bound
+// (grid_entry's general rule, an IEEE division and a select chain per coordinate: ~300 instructions per point and level -
+// see level_fast below), and the segments were not walked one level at a time per XCD until the tiles were claimed
+// instead of dealt (k_grid_encode_planes: 29.8 -> 22.5 ms per 141 M evaluations, table re-fetches 23.6 -> 9.8 GB).
 // What bounds it (round 2, tools/kbench.py, C2 dense, every XCD on the same level, profiles/kbench_r02_*.json): levels
 // 0-7 cost 1.15-1.3 ms each, then the cost climbs with the number of distinct lines a wave's 64 consecutive samples
 // touch - 1.4 / 1.7 / 2.4 / 3.0 / 3.3 ms for levels 8-12 - and saturates at 3.5 ms for levels 13-15 (4.06 with eight
