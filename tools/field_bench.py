@@ -33,7 +33,10 @@ def main():
     ap.add_argument("--dev", default="", help="development build tunables, e.g. 3=2048 (emit fine waves)")
     ap.add_argument("--scale", type=float, default=4.0,
                     help="GradScaler loss scale (bench.py settles at 4.0 on this workload: profile at the SAME state)")
+    ap.add_argument("--lib", default="", help="load this build of the library (A/B against an older one)")
     a = ap.parse_args()
+    if a.lib:
+        os.environ["MI3D_LIB"] = a.lib
     if a.dev:
         _dev_tunables(a.dev)
     import bench
