@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     const uint32_t nl = (uint32_t)__popc(level_mask);
     const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
     const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
-    const bool level_major = !role_b && fine_level_major;
+    const bool level_major = !role_b && (fine_level_major & 1u);
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
     float b00 = 0.f, b01 = 0.f, b02 = 0.f, b10 = 0.f, b11 = 0.f, b12 = 0.f;  // the tile's positions
@@ -1122,6 +1122,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
             // finds its slot taken by another entry (rare at 512 slots for a few hundred entries) walks on alone.
             auto gather8 = [&](uint32_t ex, uint32_t ey, uint32_t ez, const float (&g0)[8], const float (&g1)[8]) __attribute__((always_inline)) {
                 static_assert(kMergeSlots == 512, "the slot hash keeps 9 bits");
+#ifdef MI3D_DEV  // tools build: what the gather table's atomics cost (timing only - the sums are wrong with either bit)
+                const bool dbg_no_add = fine_level_major & 0x100u, dbg_no_cas = fine_level_major & 0x200u;
+#else
+                constexpr bool dbg_no_add = false, dbg_no_cas = false;
+#endif
 #pragma unroll
                 for (uint32_t half = 0; half < 2; ++half) {  // two batches of four probes in flight (registers)
                     uint32_t e[4], slot[4], old[4];
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j) {
                         const uint32_t k = 4 * half + j;
-                        old[j] = (g0[k] != 0.f || g1[k] != 0.f) ? atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]) : e[j];
+                        old[j] = ((g0[k] != 0.f || g1[k] != 0.f) && !dbg_no_cas) ? atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]) : e[j];
                     }
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j) {
@@ -1144,8 +1149,10 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                             placed = o == kMergeEmpty || o == e[j];
                         }
                         if (placed) {
-                            atomicAdd(&sums[2 * slot[j]], fixed_point(g0[k] * merge_scale));
-                            atomicAdd(&sums[2 * slot[j] + 1], fixed_point(g1[k] * merge_scale));
+                            if (!dbg_no_add) {
+                                atomicAdd(&sums[2 * slot[j]], fixed_point(g0[k] * merge_scale));
+                                atomicAdd(&sums[2 * slot[j] + 1], fixed_point(g1[k] * merge_scale));
+                            }
                         } else {
                             emit_record(plan, L, l, gw, e[j], g0[k], g1[k], fill, arena, grad_table, lmax);
                         }

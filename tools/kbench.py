@@ -190,6 +190,25 @@ def main():
         out = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240)
         res["scatter_fp32_P13_checksum"] = int(out.view(torch.int32).to(torch.int64).sum())   # (A/B across builds)
         del g, out
+    if "scatter_diag" in what:  # the coarse role alone, with its gather-table atomics switched off (timing only)
+        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        out = {}
+        tune(5, 0x00FF)
+        for name, flags in (("all", 0), ("no_sum_adds", 0x100), ("no_cas", 0x200), ("neither", 0x300)):
+            tune(10, flags)
+            out[name] = timeit(lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024,
+                                                                12196240), 2)
+        tune(10, -1)
+        for l in (0, 2, 4, 5, 7):
+            tune(5, 1 << l)
+            for name, flags in (("all", 0), ("neither", 0x300)):
+                tune(10, flags)
+                out[f"level{l}_{name}"] = timeit(lambda: field_ops.scatter_binned(
+                    xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240), 2)
+        tune(10, -1)
+        tune(5, -1)
+        res["scatter13_dense_coarse_role_ms"] = out
+        del g
     if "scatter_levels" in what:  # the 13-point scatter per role and per level (dev level mask), dense random gradients
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
         masks = {"all": 0xFFFF, "fine_8_15": 0xFF00, "coarse_0_7": 0x00FF}
