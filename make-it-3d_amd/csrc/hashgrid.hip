@@ -1248,6 +1248,9 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                             }
                         }
                     }
+#ifdef MI3D_DEV  // tools build: 0x1000 = cells, entries and the bin histogram only (timing only)
+                    if (fine_level_major & 0x1000u) { hist[lane] = 0u; continue; }
+#endif
                     __builtin_amdgcn_wave_barrier();
                     // lane = bin: where the bin's run starts in the staging area and in its region
                     const uint32_t cnt = hist[lane];
@@ -1290,6 +1293,9 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         const uint32_t e0 = rec.x & ((1u << kRowEntryBits) - 1u), bin = e0 >> kBinShift;
                         const uint32_t slot = i + gdelta[bin];
                         if (slot < cap) {
+#ifdef MI3D_DEV  // tools build: 0x800 = the records are sorted but not stored (timing only)
+                            if (!(fine_level_major & 0x800u))
+#endif
                             reinterpret_cast<uint4 *>(region0)[__umul24(bin, cap) + slot] = rec;
                         } else {  // region full: straight to the table
                             const float a = __uint_as_float(rec.y), b = __uint_as_float(rec.z), fx = __uint_as_float(rec.w);

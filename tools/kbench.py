@@ -208,6 +208,15 @@ def main():
         tune(10, -1)
         tune(5, -1)
         res["scatter13_dense_coarse_role_ms"] = out
+        out = {}
+        tune(5, 0xFF00)   # the fine role alone: sorted but not stored / cells, entries and histogram only
+        for name, flags in (("all", 0), ("no_region_stores", 0x800), ("pass1_only", 0x1000)):
+            tune(10, flags)
+            out[name] = timeit(lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024,
+                                                                12196240), 2)
+        tune(10, -1)
+        tune(5, -1)
+        res["scatter13_dense_fine_role_ms"] = out
         del g
     if "scatter_levels" in what:  # the 13-point scatter per role and per level (dev level mask), dense random gradients
         g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
