@@ -1253,20 +1253,30 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
 #endif
                     __builtin_amdgcn_wave_barrier();
                     // lane = bin: where the bin's run starts in the staging area and in its region
-                    const uint32_t cnt = hist[lane];
+                    const uint32_t cnt = hist[lane], g = fill_l[lane];
+                    // inclusive prefix sum over the 64 bins in registers: four DPP steps inside the 16-lane rows (zeros
+                    // shift in at a row start), then the three row totals.  (Six __shfl_up = six dependent LDS round
+                    // trips per chunk; this phase was 15.6 of the fine role's 44 ms, kbench.py --what scatter_diag.)
                     uint32_t incl = cnt;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t up = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += up;
+                    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+                    {
+                        const uint32_t r0 = __builtin_amdgcn_readlane(incl, 15), r1 = __builtin_amdgcn_readlane(incl, 31),
+                                       r2 = __builtin_amdgcn_readlane(incl, 47);
+                        incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
                     }
                     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                    const uint32_t excl = incl - cnt, g = fill_l[lane];
+                    const uint32_t excl = incl - cnt;
                     cursor[lane] = excl;
                     gdelta[lane] = g - excl;
                     if (cnt) fill_l[lane] = g + cnt;
                     hist[lane] = 0u;
                     __builtin_amdgcn_wave_barrier();
+#ifdef MI3D_DEV  // tools build: 0x2000 = stop after the scan (timing only)
+                    if (fine_level_major & 0x2000u) continue;
+#endif
                     // pass 2: the records, each to its place
 #pragma unroll
                     for (uint32_t c = 0; c < kChunkPts; ++c) {
@@ -1287,6 +1297,9 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+#ifdef MI3D_DEV  // tools build: 0x4000 = stop after the records are staged (timing only)
+                    if (fine_level_major & 0x4000u) continue;
+#endif
                     // the sorted records leave: consecutive lanes, consecutive slots of a region
                     for (uint32_t i = lane; i < total; i += kWave) {
                         const uint4 rec = stage[i];

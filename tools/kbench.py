@@ -210,7 +210,8 @@ def main():
         res["scatter13_dense_coarse_role_ms"] = out
         out = {}
         tune(5, 0xFF00)   # the fine role alone: sorted but not stored / cells, entries and histogram only
-        for name, flags in (("all", 0), ("no_region_stores", 0x800), ("pass1_only", 0x1000)):
+        for name, flags in (("all", 0), ("no_region_stores", 0x800), ("through_pass2", 0x4000), ("through_scan", 0x2000),
+                            ("pass1_only", 0x1000), ("all_again", 0)):
             tune(10, flags)
             out[name] = timeit(lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024,
                                                                 12196240), 2)
