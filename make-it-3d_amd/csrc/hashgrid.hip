@@ -1204,16 +1204,28 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                 };
                 hist[lane] = 0u;
                 for (uint32_t p0 = 0; p0 < ps.P; p0 += kChunkPts) {
-                    uint32_t ccx[kChunkPts], ccy[kChunkPts], ccz[kChunkPts];
+                    // (per chunk point: its x cell and fractions, its gradient pair, the four x-corner entries e0 and which of
+                    // them leave a pair record - kept for pass 2, which used to derive them a second time: with the
+                    // hash's two 32-bit multiplies per corner pair that was a third of the role's 820 VALU instructions
+                    // per chunk, and the role is issue-bound for its occupancy - SQ_ACTIVE_INST_ANY 0.45 of the wave
+                    // cycles at 1.5 waves per SIMD, profiles/pmc_r03_emit_roles.json)
+                    uint32_t ccx[kChunkPts], ce0[kChunkPts][4], cpm[kChunkPts];
                     float cfx[kChunkPts], cfy[kChunkPts], cfz[kChunkPts], cd0[kChunkPts], cd1[kChunkPts];
-                    bool cok[kChunkPts];
-                    // pass 1: cells, and how many records each bin gets
+                    // the chunk's gradient pairs out of the tile's (p0 is uniform and even: one select chain per chunk)
+                    uint32_t craw0[kChunkPts], craw1[kChunkPts];
+                    static_assert(kChunkPts == 2, "the pick below walks the points two at a time");
+                    craw0[0] = raw0[0]; craw0[1] = raw0[1]; craw1[0] = raw1[0]; craw1[1] = raw1[HP ? 0 : 1];
+#pragma unroll
+                    for (uint32_t k = 2; k < (uint32_t)kMaxPts; k += 2) {
+                        const uint32_t k1 = k + 1 < (uint32_t)kMaxPts ? k + 1 : k;
+                        craw0[0] = (p0 == k) ? raw0[k] : craw0[0]; craw0[1] = (p0 == k) ? raw0[k1] : craw0[1];
+                        craw1[0] = (p0 == k) ? raw1[HP ? 0 : k] : craw1[0]; craw1[1] = (p0 == k) ? raw1[HP ? 0 : k1] : craw1[1];
+                    }
+                    // pass 1: cells, entries, and how many records each bin gets
 #pragma unroll
                     for (uint32_t c = 0; c < kChunkPts; ++c) {
                         const uint32_t p = p0 + c;  // uniform
-                        uint32_t r0 = raw0[0], r1 = raw1[0];
-#pragma unroll
-                        for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
+                        const uint32_t r0 = craw0[c], r1 = craw1[c];
                         const float2 d = HP
                             ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                           (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
@@ -1222,19 +1234,35 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
                         float q[3];
                         point_of(ps, base, p < ps.P ? p : 0u, q);
+                        uint32_t cy, cz;
                         grid_cell(q[0], L.scale, ccx[c], cfx[c]);
-                        grid_cell(q[1], L.scale, ccy[c], cfy[c]);
-                        grid_cell(q[2], L.scale, ccz[c], cfz[c]);
+                        grid_cell(q[1], L.scale, cy, cfy[c]);
+                        grid_cell(q[2], L.scale, cz, cfz[c]);
                         cd0[c] = d.x; cd1[c] = d.y;
-                        cok[c] = has && finite;
-                        if (cok[c]) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
+                        const bool ok = has && finite;
+                        if (ok) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
+                        uint32_t e1s[4], pm = 0u;
+                        if (L.hashed) {  // e(x + 1) = e(x) ^ flip, flip = the bits a +1 carry changes in cx (x enters with prime 1)
+                            const uint32_t hy = cy * kPrimeY, hz = cz * kPrimeZ, hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
+                            const uint32_t yz[4] = {hy ^ hz, hy1 ^ hz, hy ^ hz1, hy1 ^ hz1};
+                            const uint32_t flip = (ccx[c] ^ (ccx[c] + 1u)) & mask;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) { ce0[c][j] = (ccx[c] ^ yz[j]) & mask; e1s[j] = ce0[c][j] ^ flip; }
+                            pm = (flip >> kBinShift) == 0u ? 0xFu : 0u;   // both entries in one bin: the same answer for all four
+                        } else {
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                pair_entries(ccx[c], cy, cz, j, ce0[c][j], e1s[j]);
+                                pm |= pairable(ce0[c][j], e1s[j]) ? 1u << j : 0u;
+                            }
+                        }
+                        cpm[c] = ok ? pm : 0u;
                         if (has) {
                             const float gx = 1.0f - cfx[c], gy = 1.0f - cfy[c], gz = 1.0f - cfz[c];
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
-                                uint32_t e0, e1;
-                                pair_entries(ccx[c], ccy[c], ccz[c], j, e0, e1);
-                                if (finite && pairable(e0, e1)) {
+                                const uint32_t e0 = ce0[c][j], e1 = e1s[j];
+                                if ((cpm[c] >> j) & 1u) {
                                     __hip_atomic_fetch_add(&hist[e0 >> kBinShift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 } else {
                                     // rare: a pair that straddles two bins leaves as two singles right away; a non-finite
@@ -1280,14 +1308,13 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     // pass 2: the records, each to its place
 #pragma unroll
                     for (uint32_t c = 0; c < kChunkPts; ++c) {
-                        if (cok[c]) {
+                        if (cpm[c]) {
                             const float gy = 1.0f - cfy[c], gz = 1.0f - cfz[c];
                             const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~ccx[c]) + 1u : 0u;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
-                                uint32_t e0, e1;
-                                pair_entries(ccx[c], ccy[c], ccz[c], j, e0, e1);
-                                if (pairable(e0, e1)) {
+                                if ((cpm[c] >> j) & 1u) {
+                                    const uint32_t e0 = ce0[c][j];
                                     const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
                                     const uint32_t pos = atomicAdd(&cursor[e0 >> kBinShift], 1u);
                                     stage[pos] = make_uint4(e0 | (t << kRowEntryBits), __float_as_uint(w * cd0[c]),
