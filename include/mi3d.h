@@ -211,12 +211,18 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
  *   out[0] samples per slice, out[1] workspace bytes one slice uses, out[2] coarse levels (gathered per tile),
  *   out[3] reduce workgroups, out[4] record-arena bytes, out[5] region counters, then 7 values per level: bins, region
  *   capacity (records), emitting waves, 1 = 16-byte x-pair records, reduce workgroups per bin, first reduce workgroup,
- *   first region counter.  out must hold 6 + 7 * n_levels values. */
+ *   first region counter.  out must hold 6 + 7 * n_levels values.
+ * mi3d_grid_level_routes: which index route the plane gather and the scatter's emit take on each level (kinds[n_levels]):
+ *   0 the general rule (any dims, any table size, any input - tcnn's grid_index as the oracle restates it), 1 dense 3-D
+ *   strided (24-bit multiplies, at most one wrap), 2 power-of-two hash (mask).  `stencil_points` != 0: the positions are
+ *   clamped stencil points (mi3d_grid_encode_points*), 0: raw positions (mi3d_hashgrid_*), which always take route 0. */
 int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
                           float per_level_scale, uint32_t log2_hashmap_size, uint32_t *n_segments, uint32_t *segments);
 int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
                            float per_level_scale, uint32_t log2_hashmap_size, size_t workspace_bytes,
                            unsigned long long *out);
+int mi3d_grid_level_routes(uint32_t n_levels, uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                           int stencil_points, int32_t *kinds);
 
 /* ------------------------------------------------------------------ Part 4: the field's MLP (sigma_net) */
 

@@ -1882,6 +1882,15 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
 
 
 // Host-side planning queries (no device work; they run without a GPU): what the two calls above will do.
+int mi3d_grid_level_routes(uint32_t n_levels, uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size,
+                           int stencil_points, int32_t *kinds) {
+    if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || kinds == nullptr) return (int)hipErrorInvalidValue;
+    GridTable T;
+    build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
+    for (uint32_t l = 0; l < T.n_levels; ++l) kinds[l] = level_fast(T.level[l], stencil_points ? 1 : 0).kind;
+    return 0;
+}
+
 int mi3d_grid_encode_plan(uint32_t n, float bound, float step, uint32_t n_levels, uint32_t base_resolution,
                           float per_level_scale, uint32_t log2_hashmap_size, uint32_t *n_segments, uint32_t *segments) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || n_segments == nullptr || segments == nullptr)

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mi3d_grid_encode_points_planes_counted": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, i32, vp],
     "mi3d_grid_encode_plan": [u32, f32, f32, u32, u32, f32, u32, vp, vp],           # host-side queries
     "mi3d_grid_scatter_plan": [u32, u32, f32, f32, u32, u32, f32, u32, C.c_size_t, vp],
+    "mi3d_grid_level_routes": [u32, u32, f32, u32, i32, vp],
     # Part 4 ------------------------------------------------------------------------------------------
     "mi3d_mlp_supported": [u32, u32, u32, u32],
     "mi3d_mlp_forward": [vp, u32, i32, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, vp, vp],

@@ -93,3 +93,26 @@ def test_scatter_plan_small_pass_and_bad_arguments(lib):
         lib.call("mi3d_grid_scatter_plan", 0, 13, 1.0, STEP, 16, 16, PLS, 19, C.c_size_t(1 << 30), out)
     with pytest.raises(lib.Mi3dError):
         lib.call("mi3d_grid_scatter_plan", 64, 17, 1.0, STEP, 16, 16, PLS, 19, C.c_size_t(1 << 30), out)
+
+
+def test_level_routes_of_the_reference_configurations(lib, oracle):
+    """Which index route each level takes (csrc/hashgrid.hip level_fast) against the oracle's level table: a level is on
+    the dense route exactly when its res^3 entries fit its table (tcnn's rule for not hashing), on the masked-hash route
+    when it is hashed into a power-of-two table, and raw positions (tcnn.Encoding's own entry points) never leave the
+    general rule."""
+    for n_levels, base, log2, pls in ((16, 16, 19, PLS), (4, 16, 19, PLS), (6, 8, 12, 1.5), (8, 16, 10, 2.0)):
+        cfg = oracle.GridConfig(n_levels=n_levels, base_resolution=base, log2_hashmap_size=log2, per_level_scale=pls)
+        kinds = (C.c_int32 * n_levels)()
+        assert lib.call("mi3d_grid_level_routes", n_levels, base, cfg.per_level_scale, log2, 1, kinds) in (0, None)
+        sizes = np.diff(cfg.offsets.astype(np.int64))
+        for l in range(n_levels):
+            res = int(cfg.resolutions[l])
+            dense = res ** 3 <= int(sizes[l])
+            want = 1 if dense else (2 if int(sizes[l]) & (int(sizes[l]) - 1) == 0 else 0)
+            assert kinds[l] == want, (n_levels, base, log2, l, res, int(sizes[l]), kinds[l])
+        raw = (C.c_int32 * n_levels)()
+        lib.call("mi3d_grid_level_routes", n_levels, base, cfg.per_level_scale, log2, 0, raw)
+        assert list(raw) == [0] * n_levels
+    k16 = (C.c_int32 * 16)()
+    lib.call("mi3d_grid_level_routes", 16, 16, PLS, 19, 1, k16)
+    assert list(k16) == [1] * 5 + [2] * 11      # the default grid: levels 0-4 dense, 5-15 hashed into 2^19 entries
