@@ -83,7 +83,7 @@ def pmc_traffic(kernel, workload, evals):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's
     evaluation count; None if not collected."""
-    for name in ("pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
+    for name in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
             return rec["hbm_bytes_per_eval"] * evals
@@ -325,6 +325,14 @@ def cpu_baseline(workload):
     return res
 
 
+def rank_views(rank, views):
+    """Which novel views a rank renders every step, and the seed of its random draws (background colour, march jitter,
+    smoothness jitter, diffusion noise): rank r takes views r * views ... r * views + views - 1 of the orbit (phi = 30 +
+    45 k degrees, mi3d/rays.py:view_rays), so the ranks of one step never render the same view, and seeds differ per rank
+    so their noise is independent (independent novel views shard with no data-path exchange)."""
+    return [rank * views + v for v in range(views)], 1234 + rank
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: become the launcher (one rank per GPU on this node)."""
     port = 29500 + (os.getpid() % 2000)
@@ -349,9 +357,16 @@ def main():
                     help="initialise the RCCL process group even at world size 1 (under torch.distributed.run): the "
                          "gradient all-reduce, the state broadcast and the occupancy broadcast then really execute")
     ap.add_argument("--cpu-baseline-only", default=None, choices=["c1", "reference", "port"], help=argparse.SUPPRESS)
+    ap.add_argument("--profile-run", action="store_true",
+                    help="the run rocprofv3 wraps (profiles/README.md): the headline's settle + warm-up + timed steps and "
+                         "NOTHING after them - no variants, no census / dense-gradient extras, no baselines - so the last "
+                         "steps/steps_run_total of every kernel's dispatches in the trace ARE the timed steps "
+                         "(tools/trace_sum.py --tail)")
     ap.add_argument("--refresh-every", type=int, default=16,
                     help="update_extra_state interval inside the timed loop (nerf/utils.py:970-972; 0 = never)")
     args = ap.parse_args()
+    if args.profile_run:
+        args.variant_steps, args.no_cpu_baseline, args.no_reference_shaped = 0, True, True
 
     if args.cpu_baseline_only:   # child process of cpu_baseline(): host cores only, no GPU
         wl = WORKLOADS[args.workload]
@@ -404,9 +419,10 @@ def main():
     bucket = dp.FlatGradBucket(model.parameters())
     guidance = sd_standin.StableDiffusionStandIn(dev)
     text_z = guidance.get_text_embeds()
-    view_rays = [R.view_rays(wl["H"], wl["W"], view=rank * views + v, device=dev) for v in range(views)]
+    view_ids, seed = rank_views(rank, views)
+    view_rays = [R.view_rays(wl["H"], wl["W"], view=v, device=dev) for v in view_ids]
     t_fixed = T_FIXED  # an int: the guidance decides its branch on the host without a device sync
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(seed)
 
     render_only = wl.get("mode") == "render"
     if render_only:
@@ -479,10 +495,16 @@ def main():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
+        if args.profile_run:   # a marker dispatch (`spin_kernel`) either side of the timed region: tools/trace_sum.py --window
+            torch.cuda._sleep(1000)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        if args.profile_run:
+            torch.cuda._sleep(1000)
+            torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -515,16 +537,43 @@ def main():
     elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of {args.steps * views} updates applied, "
         f"loss scale {info['scale_before']} -> {info['scale_after']}, peak memory {info['peak_mem_GiB']:.1f} GiB")
+    # A timed step that overflowed did NO optimizer work and halved the scale: the region is timed again (at most twice)
+    # at the scale the scaler has moved to; a line whose timed steps still did not all apply their update says so
+    # (`valid`: false) instead of passing a figure that includes skipped updates.
+    retimed = 0
+    while (not render_only and opt.fp16 and info["applied"] != args.steps * views and retimed < 2
+           and not args.profile_run):
+        retimed += 1
+        log(f"a timed step skipped its update (GradScaler overflow): timing the region again at {scaler.get_scale()}")
+        elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
+        log(f"headline (re-timed): {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of "
+            f"{args.steps * views} updates applied, loss scale {info['scale_before']} -> {info['scale_after']}")
+    steps_run_total = tries + (1 + retimed) * (args.warmup + args.steps)
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
+    dense_step = None
     if args.variant_steps > 0 and not render_only:
         e, _, _ = run("fp32", "single", args.variant_steps, 1)
         variants["records=fp32,sds_backward=single"] = 1e3 * e / args.variant_steps
         e, _, _ = run("fp32", "overlapped", args.variant_steps, 1)
         variants["records=fp32,sds_backward=overlapped"] = 1e3 * e / args.variant_steps
+        # the headline schedule with the scatter's zero-skip DEFEATED: every gradient pair that binary16 underflowed to
+        # an exact zero is replaced by +-2^-24 (the smallest binary16 subnormal) before the scatter, so the emit and the
+        # reduce process all 141 M x 16 pairs.  The replacement is one extra pass over the gradient planes, timed on its
+        # own (`densify`) and subtracted: what is reported is the step a dense-gradient workload would cost.
+        grid_ops.DENSIFY = True
+        try:
+            e, dprof, dinfo = run("fp32", "reference", args.variant_steps, 1)
+        finally:
+            grid_ops.DENSIFY = False
+        dens_ms = sum(a.elapsed_time(b) for a, b in dprof.get("densify", [])) / args.variant_steps
+        variants["dense_gradients"] = 1e3 * e / args.variant_steps - dens_ms
+        dense_step = {"ms_per_step": variants["dense_gradients"], "densify_pass_ms_subtracted": dens_ms,
+                      "scatter_ms_per_step": sum(a.elapsed_time(b) for a, b in dprof.get("scatter", [])) / args.variant_steps,
+                      "optimizer_steps_applied": dinfo["applied"], "optimizer_steps_attempted": args.variant_steps * views}
 
     # ---- untimed: which gradient pairs one step's scatters actually carry, and the scatter on dense gradients
     census, dense = None, None
-    if not render_only:
+    if not render_only and not args.profile_run:
         grid_ops.CENSUS = []
         make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)()
         torch.cuda.synchronize()
@@ -617,6 +666,7 @@ def main():
                         "optimizer_steps_applied": info["applied"], "optimizer_steps_attempted": args.steps * views,
                         "grad_scaler_scale": info["scale_before"], "grad_scaler_scale_after": info["scale_after"],
                         "grid_refreshes_in_timed_region": info["refreshes"],
+                        "steps_run_total": steps_run_total, "timed_region_repeats": retimed,
                         "parallelism": f"dp{world} (one view per GPU, flat {bucket.nbytes / 1e6:.1f} MB grad "
                                        f"all-reduce)"}),
             "variants_ms_per_step": variants,
@@ -633,6 +683,13 @@ def main():
                 ("sds_pass_point0" if k == 1 else f"regulariser_pass_{k}_points"): v for k, v in sorted(census.items())}
         if dense is not None:
             line["scatter_dense_gradients"] = dense
+        if dense_step is not None:
+            line["dense_gradient_step"] = dense_step
+        if not render_only and opt.fp16:
+            line["valid"] = info["applied"] == args.steps * views
+            if not line["valid"]:
+                line["invalid_reason"] = (f"{args.steps * views - info['applied']} timed step(s) skipped the optimizer "
+                                          f"update (GradScaler overflow) even after {retimed} re-timing(s)")
 
     # ---- baselines (rank 0 of a single-GPU run only; never part of the timed region above)
     if rank == 0 and world == 1:

@@ -31,19 +31,23 @@ WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56"
 
 
 def scatter_workspace(device, needed, cap=None):
-    """uint8 scratch of min(needed, cap, 80 % of what the device can still give) bytes from torch's caching allocator,
-    halving on an allocation failure; None when nothing useful can be had (the scatter then takes its all-atomic path).
-    Requests are whole GiB so that the sample count drifting from step to step does not leave the caching allocator with
-    a trail of slightly different multi-GiB blocks."""
+    """uint8 scratch of min(needed, cap, 80 % of what the device can still give) bytes from torch's caching allocator.
+    A small request is honoured as it is (a 2000-sample call needs 40 MiB and gets 40 MiB: it takes the record path like
+    a large one); only after an allocation FAILURE is the request halved, and below 64 MiB of a failed request nothing
+    useful can be had: None, and the scatter takes its all-atomic path.  Requests above 1 GiB are whole GiB so that the
+    sample count drifting from step to step does not leave the caching allocator with a trail of slightly different
+    multi-GiB blocks."""
     cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
     gib = 1 << 30
     free, _ = torch.cuda.mem_get_info(device)
     cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # torch can re-use this itself
     want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(0.8 * (free + cached)))
-    while want >= (64 << 20):
+    failed = False
+    while want > 0 and not (failed and want < (64 << 20)):
         try:
             return torch.empty(want, dtype=torch.uint8, device=device)
         except torch.cuda.OutOfMemoryError:
+            failed = True
             want //= 2
     return None
 
@@ -111,6 +115,9 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
     if grid_ops.CENSUS is not None:  # bench.py, one untimed step: which gradient pairs are non-zero, per level
         nz = torch.stack([(dplanes[l] != 0).any(-1).sum() for l in range(dplanes.shape[0])])
         grid_ops.CENSUS.append({"P_active": int(P_active), "rows": int(rows), "nonzero_pairs_per_level": nz})
+    if grid_ops.DENSIFY:     # bench.py, `dense_gradients` variant: defeat the emit's zero skip
+        tiny = 2.0 ** -24 if dplanes.dtype == torch.float16 else 1e-30
+        grid_ops._timed("densify", lambda: dplanes.masked_fill_(dplanes == 0, tiny), rows)
     gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
                         n_params)
     return gp, grads

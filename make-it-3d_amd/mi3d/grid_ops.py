@@ -31,6 +31,11 @@ PROFILE = None
 # gradient pairs that are not exactly zero (the emit skips the others, as the reference's atomics add zeros).
 CENSUS = None
 
+# bench.py's `dense_gradients` variant sets this: every gradient pair that underflowed to an exact zero is replaced by the
+# smallest binary16 subnormal before the scatter, so the emit cannot skip it (instrumentation, like CENSUS; never set by
+# the product).
+DENSIFY = False
+
 
 @contextlib.contextmanager
 def phase(kind):

@@ -68,3 +68,25 @@ def random_bitfield(rng, C, H, density=0.125):
     for _ in range(k):
         b &= rng.integers(0, 256, n).astype(np.uint8)
     return b
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def record_scatter_workspaces():
+    """Bytes of record arena every binned scatter of the product was handed, in call order: > 0 = the record path ran
+    (k_bin_emit + k_bin_reduce); 0 = the all-atomic fallback.  Tests of the record path assert on it: a missing arena
+    would otherwise pass through float atomics without touching the code under test."""
+    from mi3d import field_ops
+    seen, orig = [], field_ops.scatter_workspace
+
+    def spy(device, needed, cap=None):
+        ws = orig(device, needed, cap)
+        seen.append(0 if ws is None else ws.numel())
+        return ws
+    field_ops.scatter_workspace = spy
+    try:
+        yield seen
+    finally:
+        field_ops.scatter_workspace = orig

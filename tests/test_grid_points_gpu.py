@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import record_scatter_workspaces
+
 pytestmark = pytest.mark.gpu
 
 
@@ -139,13 +141,22 @@ def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace
     planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))  # [L][p*n + s][2]
     full = None
     ws = {"auto": None, "none": 0}.get(workspace, "tiny")
+    import ctypes
+    from mi3d import _lib
     if ws == "tiny":  # room for about a third of the samples per slice
-        import ctypes
-        from mi3d import _lib
         need = _lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19)
         ws = int(need)
-    g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda) if second else None, offs, P0, bound, T(planes, cuda), kcfg,
-                                 0.0034, cfg.n_params, workspace_bytes=ws).cpu().numpy()
+    with record_scatter_workspaces() as arenas:
+        g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda) if second else None, offs, P0, bound, T(planes, cuda), kcfg,
+                                     0.0034, cfg.n_params, workspace_bytes=ws).cpu().numpy()
+    if workspace == "none":
+        assert arenas == []                                   # the all-atomic path was asked for
+    else:  # the record path really ran; 'tiny' really cut the samples into several slices
+        assert len(arenas) == 1 and arenas[0] > 0, arenas
+        plan = (ctypes.c_ulonglong * (6 + 7 * 16))()
+        _lib.call("mi3d_grid_scatter_plan", n, P, 1.0, 0.0034, 16, 16, float(cfg.per_level_scale), 19,
+                  ctypes.c_size_t(arenas[0]), plan)
+        assert (plan[0] < n) == (workspace == "tiny"), (plan[0], n)
     ref = np.zeros(cfg.n_params, np.float64)
     for p, pts in enumerate(_points(x, x2, offs, P0, bound)):
         h01 = ((pts + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
@@ -204,7 +215,9 @@ def test_binned_scatter_propagates_non_finite_gradients(cuda, oracle, bad):
     for lvl in (3, 12):   # one run-merged coarse level, one fine level
         dout[777, 2, lvl, 1] = np.inf if bad == "inf" else np.nan
     planes = T(np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2)), cuda)
-    g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, planes, kcfg, 0.0034, cfg.n_params).cpu().numpy()
+    with record_scatter_workspaces() as arenas:
+        g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, planes, kcfg, 0.0034, cfg.n_params).cpu().numpy()
+    assert len(arenas) == 1 and arenas[0] > 0, arenas   # through k_bin_emit's non-finite handling, not the atomic fallback
     ref = np.zeros(cfg.n_params, np.float64)
     with np.errstate(invalid="ignore"):
         for p, pts in enumerate(_points(x, x, offs, P0, 1.0)):
