@@ -581,8 +581,16 @@ def main():
         census = {}
         for c in raw:
             nz = [int(v) for v in c["nonzero_pairs_per_level"].tolist()]
-            census[c["P_active"]] = {"rows": c["rows"], "nonzero_pair_fraction_per_level": [v / c["rows"] for v in nz],
-                                     "nonzero_pair_fraction": sum(nz) / (len(nz) * c["rows"])}
+            census[c["P_active"]] = {
+                "rows": c["rows"], "nonzero_pair_fraction_per_level": [v / c["rows"] for v in nz],
+                "nonzero_pair_fraction": sum(nz) / (len(nz) * c["rows"]),
+                # how the zeros cluster (what a lane / tile compaction in the emit could drop): per level, the share of
+                # SAMPLES with a non-zero pair on any of their stencil points, the share of 64-sample tiles with any,
+                # the share of samples that are non-zero on any level at all, and the non-zero share per stencil point
+                "samples_with_any_nonzero_point_per_level": [float(v) for v in c["samples_with_any_nonzero_point_per_level"].tolist()],
+                "tiles64_with_any_nonzero_per_level": [float(v) for v in c["tiles64_with_any_nonzero_per_level"].tolist()],
+                "samples_nonzero_on_any_level": float(c["samples_nonzero_on_any_level"]),
+                "nonzero_fraction_per_point": [float(v) for v in c["nonzero_fraction_per_point"].tolist()]}
         if rank == 0 and world == 1:
             dense = scatter_on_dense_gradients(model, view_rays[0], opt, dev)
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())

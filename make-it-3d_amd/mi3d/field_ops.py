@@ -112,9 +112,18 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
         "mi3d_mlp_backward", L.ptr(feats), plane_rows, int(feats.dtype == torch.float16), L.ptr(dh), rows,
         *[L.ptr(t) for t in ws], *dims, int(half_mode),
         L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream(x)), rows)
-    if grid_ops.CENSUS is not None:  # bench.py, one untimed step: which gradient pairs are non-zero, per level
-        nz = torch.stack([(dplanes[l] != 0).any(-1).sum() for l in range(dplanes.shape[0])])
-        grid_ops.CENSUS.append({"P_active": int(P_active), "rows": int(rows), "nonzero_pairs_per_level": nz})
+    if grid_ops.CENSUS is not None:  # bench.py, one untimed step: which gradient pairs are non-zero, and how they cluster
+        nz = (dplanes != 0).any(-1).view(dplanes.shape[0], P_active, n)          # [L, P', n]
+        per_sample = nz.any(1)                                                    # [L, n]: any stencil point of the sample
+        tiles = per_sample[:, :n - n % 64].view(per_sample.shape[0], -1, 64).any(-1)
+        grid_ops.CENSUS.append({
+            "P_active": int(P_active), "rows": int(rows),
+            "nonzero_pairs_per_level": nz.sum((1, 2)),
+            "samples_with_any_nonzero_point_per_level": per_sample.float().mean(1),
+            "tiles64_with_any_nonzero_per_level": tiles.float().mean(1),
+            "samples_nonzero_on_any_level": per_sample.any(0).float().mean(),
+            "nonzero_fraction_per_point": nz.float().mean((0, 2))})
+        del nz, per_sample, tiles
     if grid_ops.DENSIFY:     # bench.py, `dense_gradients` variant: defeat the emit's zero skip
         tiny = 2.0 ** -24 if dplanes.dtype == torch.float16 else 1e-30
         grid_ops._timed("densify", lambda: dplanes.masked_fill_(dplanes == 0, tiny), rows)
