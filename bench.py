@@ -534,6 +534,30 @@ def main():
         # then skips that optimizer update and halves, exactly as in training; the line reports how many updates were
         # applied and the scale before / after instead of aborting.
         log(f"loss scale: 4 consecutive steps applied at {scaler.get_scale()} after {tries} untimed steps; timing there")
+    # ---- untimed, BEFORE the timed region (so that a --profile-run trace ends with the timed steps): which gradient pairs
+    # one step's scatter actually carries
+    census = None
+    if not render_only:
+        grid_ops.CENSUS = []
+        make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)()
+        torch.cuda.synchronize()
+        raw, grid_ops.CENSUS = grid_ops.CENSUS, None
+        census = {}
+        for c in raw:
+            nz = [int(v) for v in c["nonzero_pairs_per_level"].tolist()]
+            census[c["P_active"]] = {
+                "rows": c["rows"], "with_deferred_point0": bool(c.get("with_deferred_point0", False)),
+                "nonzero_pair_fraction_per_level": [v / c["rows"] for v in nz],
+                "nonzero_pair_fraction": sum(nz) / (len(nz) * c["rows"]),
+                # how the zeros cluster (what a lane / tile compaction in the emit could drop): per level, the share of
+                # SAMPLES with a non-zero pair on any of their stencil points, the share of 64-sample tiles with any,
+                # the share of samples that are non-zero on any level at all, and the non-zero share per stencil point
+                "samples_with_any_nonzero_point_per_level": [float(v) for v in c["samples_with_any_nonzero_point_per_level"].tolist()],
+                "tiles64_with_any_nonzero_per_level": [float(v) for v in c["tiles64_with_any_nonzero_per_level"].tolist()],
+                "samples_nonzero_on_any_level": float(c["samples_nonzero_on_any_level"]),
+                "nonzero_fraction_per_point": [float(v) for v in c["nonzero_fraction_per_point"].tolist()]}
+        del raw
+        torch.cuda.empty_cache()
     elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of {args.steps * views} updates applied, "
         f"loss scale {info['scale_before']} -> {info['scale_after']}, peak memory {info['peak_mem_GiB']:.1f} GiB")
@@ -548,7 +572,7 @@ def main():
         elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
         log(f"headline (re-timed): {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of "
             f"{args.steps * views} updates applied, loss scale {info['scale_before']} -> {info['scale_after']}")
-    steps_run_total = tries + (1 + retimed) * (args.warmup + args.steps)
+    steps_run_total = tries + 1 + (1 + retimed) * (args.warmup + args.steps)   # settle + census + warm-up + timed
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
     dense_step = None
     if args.variant_steps > 0 and not render_only:
@@ -571,28 +595,10 @@ def main():
                       "scatter_ms_per_step": sum(a.elapsed_time(b) for a, b in dprof.get("scatter", [])) / args.variant_steps,
                       "optimizer_steps_applied": dinfo["applied"], "optimizer_steps_attempted": args.variant_steps * views}
 
-    # ---- untimed: which gradient pairs one step's scatters actually carry, and the scatter on dense gradients
-    census, dense = None, None
-    if not render_only and not args.profile_run:
-        grid_ops.CENSUS = []
-        make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)()
-        torch.cuda.synchronize()
-        raw, grid_ops.CENSUS = grid_ops.CENSUS, None
-        census = {}
-        for c in raw:
-            nz = [int(v) for v in c["nonzero_pairs_per_level"].tolist()]
-            census[c["P_active"]] = {
-                "rows": c["rows"], "nonzero_pair_fraction_per_level": [v / c["rows"] for v in nz],
-                "nonzero_pair_fraction": sum(nz) / (len(nz) * c["rows"]),
-                # how the zeros cluster (what a lane / tile compaction in the emit could drop): per level, the share of
-                # SAMPLES with a non-zero pair on any of their stencil points, the share of 64-sample tiles with any,
-                # the share of samples that are non-zero on any level at all, and the non-zero share per stencil point
-                "samples_with_any_nonzero_point_per_level": [float(v) for v in c["samples_with_any_nonzero_point_per_level"].tolist()],
-                "tiles64_with_any_nonzero_per_level": [float(v) for v in c["tiles64_with_any_nonzero_per_level"].tolist()],
-                "samples_nonzero_on_any_level": float(c["samples_nonzero_on_any_level"]),
-                "nonzero_fraction_per_point": [float(v) for v in c["nonzero_fraction_per_point"].tolist()]}
-        if rank == 0 and world == 1:
-            dense = scatter_on_dense_gradients(model, view_rays[0], opt, dev)
+    # ---- untimed: the 13-point scatter on dense random gradients
+    dense = None
+    if not render_only and not args.profile_run and rank == 0 and world == 1:
+        dense = scatter_on_dense_gradients(model, view_rays[0], opt, dev)
     m = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
     line = None
     if rank == 0:
@@ -688,7 +694,9 @@ def main():
         line["phases_ms_per_step"]["unattributed"] = line["ms_per_step"] - sum(line["phases_ms_per_step"].values())
         if census is not None:
             line["grad_nonzero_pair_fraction"] = {
-                ("sds_pass_point0" if k == 1 else f"regulariser_pass_{k}_points"): v for k, v in sorted(census.items())}
+                ("sds_pass_point0" if k == 1 else
+                 (f"both_passes_in_one_scatter_{k}_points" if v.get("with_deferred_point0") else
+                  f"regulariser_pass_{k}_points")): v for k, v in sorted(census.items())}
         if dense is not None:
             line["scatter_dense_gradients"] = dense
         if dense_step is not None:

@@ -203,6 +203,17 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                              uint32_t P, float bound, const void *dout_planes, int dout_half, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                              void *workspace, size_t workspace_bytes, float *grad_params, void *stream);
+/* ... plus a SECOND gradient pair for stencil point 0: `extra_point0_planes` [n_levels][n][2] (same element type as
+ * dout_planes; NULL = none).  The reference back-propagates twice through one forward (nerf/sd.py:171 latents.backward,
+ * then nerf/utils.py:983 scaler.scale(loss).backward()); the first pass reaches sigma / albedo of point 0 only.  Its
+ * point-0 gradient planes can be handed to the second pass's scatter here, which adds the two pairs of point 0 in fp32
+ * and scatters the sum - the same table gradient as two scatters (tcnn's atomics add the two products separately: equal
+ * up to fp32 rounding of w (a + b) against w a + w b), for one pass over the table instead of two. */
+int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                                  uint32_t P, float bound, const void *dout_planes, const void *extra_point0_planes,
+                                  int dout_half, uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
+                                  uint32_t log2_hashmap_size, float step, void *workspace, size_t workspace_bytes,
+                                  float *grad_params, void *stream);
 
 /* Host-side planning queries: no device work, callable without a GPU (tests/test_plan_cpu.py).
  * mi3d_grid_encode_plan: how mi3d_grid_encode_points_planes cuts the (level, tile-of-64-samples) list into one run of

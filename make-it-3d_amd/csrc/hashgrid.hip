@@ -990,7 +990,7 @@ __host__ __device__ inline uint32_t emit_wave_words(uint32_t n_bins) {  // 32-bi
 template <bool HP>
 __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint32_t s_begin, uint32_t s_end,
                                                              const float *__restrict__ dplanes, uint32_t plane_rows,
-                                                             uint32_t n_rows, int /*HP*/,
+                                                             uint32_t n_rows, const float *__restrict__ extra0,
                                                              GridTable T, BinPlan plan, uint32_t merge_levels,
                                                              uint32_t mask_a, uint32_t waves_a, uint32_t mask_b,
                                                              uint32_t waves_b, uint32_t fine_level_major,
@@ -1079,6 +1079,22 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     raw0[k] = v.x; raw1[k] = v.y;
                 }
             }
+            // A SECOND gradient pair for stencil point 0 (extra0: planes [L][n_rows][2] of the same element type, or null):
+            // the point-0 planes an earlier backward pass through the same forward left behind (the reference's
+            // latents.backward, nerf/sd.py:171, reaches sigma / albedo of point 0 only) ride along with this pass instead
+            // of paying for a scatter of their own; the two pairs are added in fp32 before anything else looks at them.
+            float ex0x = 0.f, ex0y = 0.f;
+            if (extra0 != nullptr) {
+                const size_t erow = (size_t)l * n_rows + (valid ? s : s_end - 1u);
+                if (HP) {
+                    const uint32_t u = reinterpret_cast<const uint32_t *>(extra0)[erow];
+                    ex0x = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu));
+                    ex0y = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+                } else {
+                    const float2 v = reinterpret_cast<const float2 *>(extra0)[erow];
+                    ex0x = v.x; ex0y = v.y;
+                }
+            }
             // coarse level: the power-of-two scale of the wave's gather table, from the tile's largest gradient (every
             // contribution is a weight <= 1 times a gradient, 6656 of them per tile: |sum| < 2^13 2^40)
             float merge_scale = 0.f;
@@ -1089,10 +1105,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                 bool bad = false;
 #pragma unroll
                 for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
-                    const float dx = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] & 0xFFFFu))
-                                                 : __uint_as_float(raw0[k]);
-                    const float dy = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] >> 16))
-                                                 : __uint_as_float(raw1[HP ? 0 : k]);
+                    float dx = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] & 0xFFFFu))
+                                           : __uint_as_float(raw0[k]);
+                    float dy = HP ? (float)__builtin_bit_cast(_Float16, (unsigned short)(raw0[k] >> 16))
+                                           : __uint_as_float(raw1[HP ? 0 : k]);
+                    if (k == 0u) { dx += ex0x; dy += ex0y; }
                     if (valid && k < ps.P) {
                         bad |= !(fabsf(dx) <= 3.4028234663852886e38f && fabsf(dy) <= 3.4028234663852886e38f);
                         tmax = fmaxf(tmax, fmaxf(fabsf(dx), fabsf(dy)));
@@ -1226,10 +1243,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     for (uint32_t c = 0; c < kChunkPts; ++c) {
                         const uint32_t p = p0 + c;  // uniform
                         const uint32_t r0 = craw0[c], r1 = craw1[c];
-                        const float2 d = HP
+                        float2 d = HP
                             ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                           (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                             : make_float2(__uint_as_float(r0), __uint_as_float(r1));
+                        if (p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform)
                         const bool has = valid && p < ps.P && (d.x != 0.f || d.y != 0.f);
                         const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
                         float q[3];
@@ -1359,10 +1377,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
                     for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
-                    const float2 d = HP
+                    float2 d = HP
                         ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                       (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                         : make_float2(__uint_as_float(r0), __uint_as_float(r1));
+                    if (p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform)
                     float q[3];
                     point_of(ps, base, p, q);
                     float fx, fy, fz;
@@ -1435,10 +1454,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                 uint32_t r0 = raw0[0], r1 = raw1[0];
 #pragma unroll
                 for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
-                const float2 d = HP
+                float2 d = HP
                     ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                   (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                     : make_float2(__uint_as_float(r0), __uint_as_float(r1));
+                if (p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform)
                 const bool has = valid && (d.x != 0.f || d.y != 0.f);
                 const unsigned long long act = __ballot(has);
                 if (act == 0ull) continue;
@@ -1796,12 +1816,23 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
                              uint32_t P, float bound, const void *dout_planes_v, int dout_half, uint32_t n_levels,
                              uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size, float step,
                              void *workspace, size_t workspace_bytes, float *grad_params, void *stream) {
+    return mi3d_grid_scatter_binned_plus(x, x2, n, offsets_host, P0, P, bound, dout_planes_v, nullptr, dout_half, n_levels,
+                                         base_resolution, per_level_scale, log2_hashmap_size, step, workspace,
+                                         workspace_bytes, grad_params, stream);
+}
+
+int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, const float *offsets_host, uint32_t P0,
+                                  uint32_t P, float bound, const void *dout_planes_v, const void *extra_point0_planes,
+                                  int dout_half, uint32_t n_levels, uint32_t base_resolution, float per_level_scale,
+                                  uint32_t log2_hashmap_size, float step, void *workspace, size_t workspace_bytes,
+                                  float *grad_params, void *stream) {
     if (n_levels == 0 || n_levels > MI3D_MAX_LEVELS || P == 0 || P > MI3D_MAX_POINTS || P0 > P ||
         (P0 < P && x2 == nullptr))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     hipStream_t st = as_stream(stream);
     const float *dout_planes = reinterpret_cast<const float *>(dout_planes_v);
+    const float *extra0 = reinterpret_cast<const float *>(extra_point0_planes);
     GridTable T;
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const PointSet ps = make_points(x, x2, offsets_host, P0, P, bound, 1);
@@ -1827,14 +1858,20 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         if (workspace != nullptr && workspace_bytes >= rep_bytes && rep_bytes < ((size_t)2 << 30)) {
             float *rep = reinterpret_cast<float *>(workspace);
             (void)hipMemsetAsync(rep, 0, rep_bytes, st);
-            const int err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, rep, st, 0xFFFFFFFFu, plane_rows,
-                                           kReplicas, (size_t)T.n_entries * 2, dout_half);
+            int err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, rep, st, 0xFFFFFFFFu, plane_rows,
+                                     kReplicas, (size_t)T.n_entries * 2, dout_half);
+            if (!err && extra0 != nullptr)   // (the atomic kernels take one pair per point: point 0 again, on its own)
+                err = launch_scatter(make_points(x, nullptr, offsets_host, 1, 1, bound, 1), n, nullptr, extra0, T,
+                                     merge_atomic, rep, st, 0xFFFFFFFFu, n, kReplicas, (size_t)T.n_entries * 2, dout_half);
             hipLaunchKernelGGL(k_replica_reduce, dim3((T.n_entries * 2 + 255) / 256), dim3(256), 0, st, rep, kReplicas,
                                (size_t)T.n_entries * 2, T.n_entries * 2, grad_params);
             return err ? err : (int)hipGetLastError();
         }
-        return launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, grad_params, st, 0xFFFFFFFFu, plane_rows, 1, 0,
-                              dout_half);
+        const int err = launch_scatter(ps, n, nullptr, dout_planes, T, merge_atomic, grad_params, st, 0xFFFFFFFFu,
+                                       plane_rows, 1, 0, dout_half);
+        if (err || extra0 == nullptr) return err;
+        return launch_scatter(make_points(x, nullptr, offsets_host, 1, 1, bound, 1), n, nullptr, extra0, T, merge_atomic,
+                              grad_params, st, 0xFFFFFFFFu, n, 1, 0, dout_half);
     }
     char *arena = reinterpret_cast<char *>(workspace);
     uint32_t *counts = reinterpret_cast<uint32_t *>(arena + plan.total_bytes);
@@ -1864,11 +1901,11 @@ int mi3d_grid_scatter_binned(const float *x, const float *x2, uint32_t n, const 
         {
             const dim3 eg((fine_waves + coarse_waves) / kWaves), eb(kWave * kWaves);
             if (dout_half)
-                hipLaunchKernelGGL(k_bin_emit<true>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, 1, T,
+                hipLaunchKernelGGL(k_bin_emit<true>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, extra0, T,
                                    plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
                                    reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
             else
-                hipLaunchKernelGGL(k_bin_emit<false>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, 0, T,
+                hipLaunchKernelGGL(k_bin_emit<false>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, extra0, T,
                                    plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
                                    reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         }

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "mi3d_grid_scatter_points": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, vp],
     "mi3d_grid_encode_points_planes": [vp, vp, u32, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, i32, vp],
     "mi3d_grid_scatter_binned": [vp, vp, u32, vp, u32, u32, f32, vp, i32, u32, u32, f32, u32, f32, vp, C.c_size_t, vp, vp],
+    "mi3d_grid_scatter_binned_plus": [vp, vp, u32, vp, u32, u32, f32, vp, vp, i32, u32, u32, f32, u32, f32, vp, C.c_size_t,
+                                      vp, vp],
     "mi3d_grid_encode_points_planes_counted": [vp, vp, u32, vp, vp, u32, u32, f32, vp, u32, u32, f32, u32, f32, vp, i32, vp],
     "mi3d_grid_encode_plan": [u32, f32, f32, u32, u32, f32, u32, vp, vp],           # host-side queries
     "mi3d_grid_scatter_plan": [u32, u32, f32, f32, u32, u32, f32, u32, C.c_size_t, vp],

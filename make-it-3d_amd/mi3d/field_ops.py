@@ -52,16 +52,19 @@ def scatter_workspace(device, needed, cap=None):
     return None
 
 
-def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None):
+def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None, extra0=None):
     """grad_params [n_params] from level-major feature-gradient planes [L][P*n][2], rows point-major (C ABI:
-    mi3d_grid_scatter_binned).  workspace_bytes: None = scratch sized by scatter_workspace; 0 = force the all-atomic
-    path."""
+    mi3d_grid_scatter_binned_plus).  workspace_bytes: None = scratch sized by scatter_workspace; 0 = force the all-atomic
+    path.  extra0: a second set of planes [L][n][2] for stencil point 0 (same dtype), added to point 0's pairs."""
     offs, offs_p = grid_ops._offs_arg(offsets)
     P, n = offs.shape[0], x.shape[0]
     if dplanes.dtype not in (torch.float32, torch.float16) or not dplanes.is_cuda or not dplanes.is_contiguous():
         raise L.Mi3dError("dplanes must be a contiguous float32 / float16 GPU tensor")
     if dplanes.numel() != cfg["n_levels"] * n * P * 2:
         raise L.Mi3dError(f"dplanes has {dplanes.numel()} elements, expected [L={cfg['n_levels']}][{P * n}][2]")
+    if extra0 is not None and (extra0.dtype != dplanes.dtype or not extra0.is_cuda or not extra0.is_contiguous()
+                               or extra0.numel() != cfg["n_levels"] * n * 2 or extra0.device != dplanes.device):
+        raise L.Mi3dError(f"extra0 must be contiguous {dplanes.dtype} planes [L={cfg['n_levels']}][{n}][2] on the same GPU")
     grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
     lib = L.lib()
     ws, ws_bytes = None, 0
@@ -74,8 +77,9 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
         ws_bytes = ws.numel() if ws is not None else 0
     with L.on(x):
         grid_ops._timed("scatter", lambda: L.call(
-            "mi3d_grid_scatter_binned", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
-            int(dplanes.dtype == torch.float16), cfg["n_levels"], cfg["base_resolution"], cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
+            "mi3d_grid_scatter_binned_plus", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
+            L.ptr(extra0), int(dplanes.dtype == torch.float16), cfg["n_levels"], cfg["base_resolution"],
+            cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
             L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
     return grad
 
@@ -100,9 +104,9 @@ def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mo
     return feats, h, dims
 
 
-def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step, n_params, half_mode, P_active):
-    """(grad_params, [dW1, db1, dW2, db2, dW3, db3]) from dh [P_active*n, 4]: the MLP backward and the scatter run over
-    the first P_active points of the stencil only."""
+def _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active):
+    """(dplanes [L][P_active*n][2], [dW1, db1, dW2, db2, dW3, db3]) from dh [P_active*n, 4]: the MLP backward over the
+    first P_active points of the stencil only."""
     n = x.shape[0]
     rows, plane_rows = P_active * n, feats.shape[1]
     # binary16 gradient planes under autocast: what the reference's binary16 dgrad GEMM hands the encoder's backward
@@ -112,12 +116,20 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
         "mi3d_mlp_backward", L.ptr(feats), plane_rows, int(feats.dtype == torch.float16), L.ptr(dh), rows,
         *[L.ptr(t) for t in ws], *dims, int(half_mode),
         L.ptr(dplanes), rows, *[L.ptr(g) for g in grads], L.stream(x)), rows)
+    return dplanes, grads
+
+
+def _scatter_planes(dplanes, x, x2, offs, P0, bound, cfg, step, n_params, P_active, extra0=None):
+    n = x.shape[0]
+    rows = P_active * n
     if grid_ops.CENSUS is not None:  # bench.py, one untimed step: which gradient pairs are non-zero, and how they cluster
         nz = (dplanes != 0).any(-1).view(dplanes.shape[0], P_active, n)          # [L, P', n]
+        if extra0 is not None:
+            nz[:, 0] |= (extra0 != 0).any(-1)
         per_sample = nz.any(1)                                                    # [L, n]: any stencil point of the sample
         tiles = per_sample[:, :n - n % 64].view(per_sample.shape[0], -1, 64).any(-1)
         grid_ops.CENSUS.append({
-            "P_active": int(P_active), "rows": int(rows),
+            "P_active": int(P_active), "rows": int(rows), "with_deferred_point0": extra0 is not None,
             "nonzero_pairs_per_level": nz.sum((1, 2)),
             "samples_with_any_nonzero_point_per_level": per_sample.float().mean(1),
             "tiles64_with_any_nonzero_per_level": tiles.float().mean(1),
@@ -127,9 +139,89 @@ def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step
     if grid_ops.DENSIFY:     # bench.py, `dense_gradients` variant: defeat the emit's zero skip
         tiny = 2.0 ** -24 if dplanes.dtype == torch.float16 else 1e-30
         grid_ops._timed("densify", lambda: dplanes.masked_fill_(dplanes == 0, tiny), rows)
-    gp = scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
-                        n_params)
-    return gp, grads
+    return scatter_binned(x, x2 if P_active > P0 else None, offs[:P_active], min(P0, P_active), bound, dplanes, cfg, step,
+                          n_params, extra0=extra0)
+
+
+def _backward_mlp_scatter(dh, feats, ws, dims, x, x2, offs, P0, bound, cfg, step, n_params, half_mode, P_active):
+    """(grad_params, [dW1, db1, dW2, db2, dW3, db3]) from dh [P_active*n, 4]: the MLP backward and the scatter run over
+    the first P_active points of the stencil only."""
+    dplanes, grads = _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active)
+    return _scatter_planes(dplanes, x, x2, offs, P0, bound, cfg, step, n_params, P_active), grads
+
+
+# ---- the point-0 pass of a two-backward schedule, deferred (grid_ops.DEFER_POINT0) --------------------------------------
+
+def _accumulates_into_grad(param):
+    """True when the backward pass now running will ACCUMULATE into param.grad (Tensor.backward), False when it hands
+    the gradient back to a caller (torch.autograd.grad: the engine refuses the question for a leaf then) or cannot say."""
+    try:
+        node = param.__dict__.get("_mi3d_acc_node")
+        if node is None:
+            with torch.enable_grad():
+                node = param.expand_as(param).grad_fn.next_functions[0][0]
+            param.__dict__["_mi3d_acc_node"] = node
+        return bool(torch._C._will_engine_execute_node(node))
+    except Exception:  # noqa: BLE001 - any doubt: scatter now
+        return False
+
+
+def _may_defer(param, P, P_active):
+    """Park this pass's point-0 planes instead of scattering them?  Only when every one of these holds: the switch is on;
+    the table is a GridParameter (its `.grad` completes the scatter for any reader); the pass stops at point 0 of a wider
+    stencil; it runs under retain_graph=True, i.e. the caller announced another pass through this forward (nerf/sd.py:171
+    does); and the engine is accumulating into `.grad` rather than returning gradients."""
+    if not (grid_ops.DEFER_POINT0 and isinstance(param, grid_ops.GridParameter) and P_active == 1 and P > 1):
+        return False
+    try:
+        keep = torch._C._autograd._get_current_graph_task_keep_graph()
+    except Exception:  # noqa: BLE001
+        return False
+    return bool(keep) and _accumulates_into_grad(param)
+
+
+def _park(param, key, item):
+    pend = param.__dict__.setdefault("_mi3d_pending", [])
+    older = [it for it in pend if it["key"] == key]
+    if older:                       # a second point-0 pass through the same forward: complete the first one now
+        flush_pending(param, key)
+    item["key"] = key
+    item["event"] = torch.cuda.current_stream(item["x"].device).record_event()
+    pend.append(item)
+
+
+def _take_parked(param, key):
+    """The planes an earlier pass through the forward `key` parked on `param` (None if none), removed from the list."""
+    pend = None if param is None else param.__dict__.get("_mi3d_pending")
+    if not pend:
+        return None
+    for i, it in enumerate(pend):
+        if it["key"] == key:
+            del pend[i]
+            torch.cuda.current_stream(it["x"].device).wait_event(it["event"])
+            return it["dplanes"]
+    return None
+
+
+@torch.no_grad()
+def flush_pending(param, key=None):
+    """Scatter what is parked on `param` (all of it, or the forward `key`'s) and accumulate it into the real `.grad`."""
+    pend = param.__dict__.get("_mi3d_pending")
+    if not pend:
+        return
+    items = [it for it in pend if key is None or it["key"] == key]
+    pend[:] = [it for it in pend if not (key is None or it["key"] == key)]
+    for it in items:
+        x = it["x"]
+        with L.on(x):
+            torch.cuda.current_stream(x.device).wait_event(it["event"])
+            g = _scatter_planes(it["dplanes"], x, None, it["offs"], it["P0"], it["bound"], it["cfg"], it["step"],
+                                it["n_params"], 1)
+        real = torch.Tensor.grad.__get__(param)
+        if real is None:
+            torch.Tensor.grad.__set__(param, g.view_as(param))
+        else:
+            real.add_(g.view_as(real))      # in place: `.grad` may be a view into an all-reduce bucket
 
 
 class _FieldStencil(Function):
@@ -283,6 +375,10 @@ class _Field(Function):
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, h, *ws)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
                     int(half_mode), float(blob_density), float(blob_radius), float(epsilon))
+        # the table as the caller's parameter object (custom_fwd leaves an fp32 tensor as it is): where a point-0 pass
+        # parks its planes for the pass that follows it through this forward (grid_ops.DEFER_POINT0)
+        ctx.param_ref = params if isinstance(params, grid_ops.GridParameter) else None
+        ctx.forward_key = object()
         ctx.set_materialize_grads(False)
         if normal2 is None:
             return sigma, albedo, normal
@@ -298,11 +394,21 @@ class _Field(Function):
         if all(g is None for g in grads):
             return none
         P_active = _active_points(offs.shape[0], grads)
+        param = getattr(ctx, "param_ref", None)
         with L.on(x):
             dh = _head_backward(h, x, x2 if has_x2 else None, offs, bound, blob_density, blob_radius, epsilon, grads,
                                 P_active)
-            gp, wg = _backward_mlp_scatter(dh, feats, ws, dims, x, x2 if has_x2 else None, offs, P0, bound, cfg, step,
-                                           n_params, half_mode, P_active)
+            dplanes, wg = _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active)
+            if _may_defer(param, offs.shape[0], P_active):
+                # nerf/sd.py:171's pass: nothing is scattered now - the planes wait for the pass that follows (or for
+                # the first reader of encoder.params.grad)
+                _park(param, ctx.forward_key, dict(dplanes=dplanes, x=x, offs=offs, P0=P0, bound=bound, cfg=cfg,
+                                                   step=step, n_params=n_params))
+                gp = None
+            else:
+                extra0 = _take_parked(param, ctx.forward_key) if P_active > 1 else None
+                gp = _scatter_planes(dplanes, x, x2 if has_x2 else None, offs, P0, bound, cfg, step, n_params, P_active,
+                                     extra0=extra0)
         return (gp, *wg, *none[:11])
 
 

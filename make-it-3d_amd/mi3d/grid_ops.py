@@ -64,6 +64,43 @@ def _timed(kind, launch, evals):
     PROFILE.setdefault(kind + "_evals", []).append(evals)
 
 
+# The reference's SDS step back-propagates TWICE through one forward (nerf/sd.py:171 `latents.backward(gradient=grad,
+# retain_graph=True)`, then nerf/utils.py:983 `scaler.scale(loss).backward()`).  The first pass reaches the field through
+# the image only: sigma / albedo of stencil point 0.  With DEFER_POINT0 the fused field node does NOT scatter that pass's
+# point-0 gradient planes on their own: it parks them on the hash table's parameter (a GridParameter) and the second
+# pass's scatter takes them along (mi3d_grid_scatter_binned_plus) - one walk over the table instead of two.  Whatever
+# is still parked when somebody READS `encoder.params.grad` is scattered then (GridParameter.grad), so every reader -
+# GradScaler.unscale_, clip_grad_norm_, the optimizer, an all-reduce bucket - sees the complete gradient, second backward
+# or not.  Set to False to scatter every pass immediately (round 3's behaviour).
+DEFER_POINT0 = True
+
+
+class GridParameter(torch.nn.Parameter):
+    """The hash table as a parameter (`tinycudann.Encoding.params`): an nn.Parameter whose `.grad` first scatters the
+    gradient planes a backward pass may have parked on it (DEFER_POINT0 above).  autograd itself accumulates through the
+    C++ accessor and is not affected; assigning `.grad` (zero_grad(set_to_none=True), a bucket view) drops what is
+    parked, as it replaces what was accumulated."""
+
+    def __new__(cls, data=None, requires_grad=True):
+        if data is None:
+            data = torch.empty(0)
+        return torch.Tensor._make_subclass(cls, data, requires_grad)
+
+    @property
+    def grad(self):
+        if self.__dict__.get("_mi3d_pending"):
+            from . import field_ops
+            field_ops.flush_pending(self)
+        return torch.Tensor.grad.__get__(self)
+
+    @grad.setter
+    def grad(self, value):
+        pend = self.__dict__.get("_mi3d_pending")
+        if pend:
+            pend.clear()
+        torch.Tensor.grad.__set__(self, value)
+
+
 def _offs_arg(offsets):
     offsets = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1, 3)
     return offsets, offsets.ctypes.data_as(C.c_void_p)

@@ -212,50 +212,8 @@ class NeRFRenderer(nn.Module):
                 if smooth:
                     out["loss_smooth"] = (normals - normals_jitter).abs().mean()
         else:
-            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
-            depth = torch.zeros(N, dtype=torch.float32, device=device)
-            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            normal = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            # The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list, the row
-            # count - kept on the DEVICE (raymarching.*_ctl, C ABI Part 1b): every round is launched for an upper bound of
-            # the alive count, every kernel of the round - march, gather, MLP, head, composite, compaction - reads the true
-            # counts from the control block and skips what lies beyond them, and the host reads them back only every
-            # `sync_every` rounds (every round while the alive count is collapsing), instead of one boolean-mask
-            # synchronisation per round.  Same arithmetic, same round structure, same results.
-            rays_t = nears.clone()
-            align, sync_every = 128, 8
-            rows_cap = N + 2 * align
-            xyzs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
-            dirs = torch.zeros(rows_cap, 3, dtype=torch.float32, device=device)
-            deltas = torch.zeros(rows_cap, 2, dtype=torch.float32, device=device)
-            noises = torch.rand(N, dtype=torch.float32, device=device) if perturb else None
-            ctl, alive = raymarching.infer_begin(N, device, align)
-            spare = torch.empty_like(alive)
-            n_ub, done_lb, since_sync, next_sync = N, 0, 0, sync_every
-            while n_ub > 0 and done_lb < max_steps:
-                rows_ub = min(N, 8 * n_ub)
-                rows_ub += align - rows_ub % align       # >= the device's n_alive * n_step rounded past `align`
-                raymarching.march_rays_ctl(ctl, n_ub, alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
-                                           self.cascade, self.grid_size, fars, xyzs, dirs, deltas, noises, dt_gamma,
-                                           max_steps)
-                self._infer_rows = ctl[2:3]              # the round's true row count, on the device (field_ops.field_rows)
-                try:
-                    sigmas, rgbs, normals = self(xyzs[:rows_ub], dirs[:rows_ub], light_d, ratio=ambient_ratio,
-                                                 shading=shading)
-                finally:
-                    self._infer_rows = None
-                raymarching.composite_rays_ctl(ctl, n_ub, alive, rays_t, sigmas, rgbs, (normals + 1) / 2,
-                                               deltas[:rows_ub], weights_sum, depth, image, normal, T_thresh)
-                raymarching.compact_alive_ctl(ctl, alive, spare, N, align, max_steps)
-                alive, spare = spare, alive
-                done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
-                since_sync += 1
-                if since_sync >= next_sync:
-                    state = ctl.tolist()                 # the only synchronisation
-                    # while rays are dying quickly the host's bound goes stale quickly (and every round evaluates the
-                    # field on its rows_ub rows): read the count back every round then, every `sync_every` otherwise
-                    next_sync = 1 if 4 * state[0] < 3 * n_ub else sync_every
-                    n_ub, done_lb, since_sync = state[0], state[3], 0
+            weights_sum, depth, image, normal = self._infer_loop(rays_o, rays_d, nears, fars, light_d, ambient_ratio,
+                                                                 shading, perturb, dt_gamma, max_steps, T_thresh)
 
         if bg_color is None:
             bg_color = 1
@@ -274,6 +232,138 @@ class NeRFRenderer(nn.Module):
         if not self.training:
             out["normal"] = normal
         return out
+
+    # --- the inference loop (renderer.py:526-551), driven from the device ------------------------------------------
+    # rounds per captured graph (0 = launch every round from the host and read the alive count back every 8 rounds, the
+    # round-3 loop).  An even number: the alive / spare lists swap every round.
+    infer_graph_rounds = 32
+
+    def _infer_round(self, st, n_ub, light_d, ambient_ratio, shading, dt_gamma, max_steps, T_thresh):
+        """One round of the reference loop - march n_step steps for every alive ray, evaluate the field on those rows,
+        composite, compact the alive list, plan the next round - launched for an UPPER BOUND n_ub of the alive count:
+        every kernel (march, gather, MLP, head, composite, compaction) reads the true counts from the device control
+        block and skips what lies beyond them."""
+        N, align = st["N"], st["align"]
+        rows_ub = min(N, 8 * n_ub)
+        rows_ub += align - rows_ub % align       # >= the device's n_alive * n_step rounded past `align`
+        alive, spare = (st["alive"], st["spare"]) if st["parity"] == 0 else (st["spare"], st["alive"])
+        raymarching.march_rays_ctl(st["ctl"], n_ub, alive, st["rays_t"], st["rays_o"], st["rays_d"], self.bound,
+                                   self.density_bitfield, self.cascade, self.grid_size, st["fars"], st["xyzs"],
+                                   st["dirs"], st["deltas"], st["noises"], dt_gamma, max_steps)
+        self._infer_rows = st["ctl"][2:3]        # the round's true row count, on the device (field_ops.field_rows)
+        try:
+            sigmas, rgbs, normals = self(st["xyzs"][:rows_ub], st["dirs"][:rows_ub], light_d, ratio=ambient_ratio,
+                                         shading=shading)
+        finally:
+            self._infer_rows = None
+        raymarching.composite_rays_ctl(st["ctl"], n_ub, alive, st["rays_t"], sigmas, rgbs, (normals + 1) / 2,
+                                       st["deltas"][:rows_ub], st["weights_sum"], st["depth"], st["image"],
+                                       st["normal"], T_thresh)
+        raymarching.compact_alive_ctl(st["ctl"], alive, spare, N, align, max_steps)
+        st["parity"] ^= 1
+
+    def _infer_state(self, N, device, perturb):
+        """Caller-owned buffers of the loop for N rays, kept across renders: a captured graph of rounds holds their
+        addresses."""
+        cache = self.__dict__.setdefault("_infer_cache", {})
+        st = cache.get((N, str(device)))
+        if st is None:
+            align = 128
+            rows_cap = N + 2 * align
+            f32 = dict(dtype=torch.float32, device=device)
+            st = {"N": N, "align": align, "graphs": {},
+                  "rays_o": torch.empty(N, 3, **f32), "rays_d": torch.empty(N, 3, **f32),
+                  "fars": torch.empty(N, **f32), "rays_t": torch.empty(N, **f32), "light_d": torch.empty(3, **f32),
+                  "xyzs": torch.zeros(rows_cap, 3, **f32), "dirs": torch.zeros(rows_cap, 3, **f32),
+                  "deltas": torch.zeros(rows_cap, 2, **f32), "noise_buf": torch.zeros(N, **f32),
+                  "ctl": torch.zeros(8, dtype=torch.int32, device=device),
+                  "alive": torch.empty(N, dtype=torch.int32, device=device),
+                  "spare": torch.empty(N, dtype=torch.int32, device=device),
+                  "weights_sum": torch.zeros(N, **f32), "depth": torch.zeros(N, **f32),
+                  "image": torch.zeros(N, 3, **f32), "normal": torch.zeros(N, 3, **f32)}
+            cache.clear()                       # one ray count at a time: the buffers of an older one are released
+            cache[(N, str(device))] = st
+        st["noises"] = st["noise_buf"] if perturb else None
+        st["parity"] = 0
+        return st
+
+    def _infer_loop(self, rays_o, rays_d, nears, fars, light_d, ambient_ratio, shading, perturb, dt_gamma, max_steps,
+                    T_thresh):
+        """The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list, the row
+        count - kept on the DEVICE (raymarching.*_ctl, C ABI Part 1b) and the HOST OUT OF THE LOOP: `infer_graph_rounds`
+        rounds are captured once as a hipGraph (torch.cuda.CUDAGraph: march_ctl -> counted gather / MLP / head ->
+        composite_ctl -> compact_ctl, x 32) per upper bound of the alive count (N, N/2, N/4, ...), and replayed until a
+        single end-of-batch read of the control block says no ray is alive: one D2H per 32 rounds instead of one boolean-
+        mask synchronisation per round in the reference (one per 8 rounds in round 3).  Rounds that run after the last
+        ray died see n_alive = 0 on the device and do nothing.  Same kernels, same round structure, same results as the
+        host-launched loop (tests/test_raymarching_gpu.py compares the two bit for bit)."""
+        N, device = rays_o.shape[0], rays_o.device
+        R = int(self.infer_graph_rounds)
+        use_graph = R > 0 and R % 2 == 0 and rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
+        st = self._infer_state(N, device, perturb)
+        st["rays_o"].copy_(rays_o)
+        st["rays_d"].copy_(rays_d)
+        st["fars"].copy_(fars)
+        st["rays_t"].copy_(nears)
+        st["light_d"].copy_(light_d.reshape(3).float())
+        if perturb:
+            st["noise_buf"].copy_(torch.rand(N, dtype=torch.float32, device=device))
+        for k in ("weights_sum", "depth", "image", "normal"):
+            st[k].zero_()
+        raymarching.infer_begin(N, device, st["align"], st["ctl"], st["alive"])
+        args = (st["light_d"], float(ambient_ratio), shading, float(dt_gamma), int(max_steps), float(T_thresh))
+        stats = {"rounds_launched": 0, "host_reads": 0, "graph_replays": 0, "graphs_captured": 0}
+
+        if not use_graph:
+            sync_every = 8
+            n_ub, done_lb, since_sync, next_sync = N, 0, 0, sync_every
+            while n_ub > 0 and done_lb < max_steps:
+                self._infer_round(st, n_ub, *args)
+                stats["rounds_launched"] += 1
+                done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
+                since_sync += 1
+                if since_sync >= next_sync:
+                    state = st["ctl"].tolist()           # the only synchronisation
+                    stats["host_reads"] += 1
+                    # while rays are dying quickly the host's bound goes stale quickly (and every round evaluates the
+                    # field on its rows_ub rows): read the count back every round then, every `sync_every` otherwise
+                    next_sync = 1 if 4 * state[0] < 3 * n_ub else sync_every
+                    n_ub, done_lb, since_sync = state[0], state[3], 0
+        else:
+            from . import grid_ops
+            key_tail = (shading, float(ambient_ratio), float(dt_gamma), int(max_steps), float(T_thresh), bool(perturb),
+                        torch.is_autocast_enabled("cuda"), self.density_bitfield.data_ptr(),
+                        tuple(p.data_ptr() for p in self.parameters()))
+            alive = N
+            while alive > 0:
+                n_ub = N
+                while n_ub // 2 >= max(alive, 1024):     # the smallest bucket N / 2^k (>= 1024) that covers the alive count
+                    n_ub //= 2
+                g = st["graphs"].get((n_ub,) + key_tail)
+                if g is None:
+                    # two eager rounds first (real rounds: they advance the loop): every kernel of a round has then run
+                    # in this process, so the capture meets no first-use initialisation; two, so the lists' parity holds
+                    for _ in range(2):
+                        self._infer_round(st, n_ub, *args)
+                    stats["rounds_launched"] += 2
+                    profile, grid_ops.PROFILE = grid_ops.PROFILE, None   # (no event records inside a capture)
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            for _ in range(R):
+                                self._infer_round(st, n_ub, *args)
+                    finally:
+                        grid_ops.PROFILE = profile
+                    st["graphs"] = {k: v for k, v in st["graphs"].items() if k[1:] == key_tail}  # stale keys: other weights
+                    st["graphs"][(n_ub,) + key_tail] = g
+                    stats["graphs_captured"] += 1
+                g.replay()
+                stats["rounds_launched"] += R
+                stats["graph_replays"] += 1
+                alive = st["ctl"].tolist()[0]            # the only synchronisation: once per R rounds
+                stats["host_reads"] += 1
+        self.infer_stats = stats
+        return st["weights_sum"].clone(), st["depth"].clone(), st["image"].clone(), st["normal"].clone()
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):

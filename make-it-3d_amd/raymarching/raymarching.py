@@ -309,10 +309,16 @@ composite_sdf_rays = _composite_sdf_rays.apply
 # mi3d.renderer.NeRFRenderer.run_cuda uses them; the reference's own loop keeps working on march_rays / composite_rays.
 
 
-def infer_begin(N, device, align=128):
-    """(ctl int32[8], rays_alive int32[N] = 0..N-1) for a fresh loop over N rays."""
-    ctl = torch.zeros(8, dtype=torch.int32, device=device)
-    rays_alive = torch.empty(N, dtype=torch.int32, device=device)
+def infer_begin(N, device, align=128, ctl=None, rays_alive=None):
+    """(ctl int32[8], rays_alive int32[N] = 0..N-1) for a fresh loop over N rays; `ctl` / `rays_alive`: re-initialise
+    these caller-owned buffers instead of allocating (a captured graph of rounds keeps their addresses)."""
+    if ctl is None:
+        ctl = torch.zeros(8, dtype=torch.int32, device=device)
+    else:
+        L.dev_typed(ctl, "ctl", torch.int32).zero_()
+    if rays_alive is None:
+        rays_alive = torch.empty(N, dtype=torch.int32, device=device)
+    L.dev_typed(rays_alive, "rays_alive", torch.int32)
     L.launch("mi3d_infer_begin", ctl, L.ptr(ctl), L.ptr(rays_alive), int(N), int(max(align, 0)))
     return ctl, rays_alive
 

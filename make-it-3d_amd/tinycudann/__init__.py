@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from mi3d import _lib as L
+from mi3d.grid_ops import GridParameter
 
 __all__ = ["Encoding", "Network", "NetworkWithInputEncoding"]
 
@@ -79,7 +80,8 @@ class Encoding(nn.Module):
         total, self.offsets, self.resolutions, self.scales = grid_levels(**self.cfg)
         self.n_output_dims = self.cfg["n_levels"] * 2
         g = torch.Generator().manual_seed(seed)
-        self.params = nn.Parameter((torch.rand(total * 2, generator=g) * 2 - 1) * 1e-4)  # tcnn: U(-1e-4, 1e-4)
+        # tcnn: U(-1e-4, 1e-4).  (A GridParameter IS an nn.Parameter; its `.grad` completes a deferred scatter first.)
+        self.params = GridParameter((torch.rand(total * 2, generator=g) * 2 - 1) * 1e-4)
 
     def forward(self, x):
         if not x.is_cuda:

@@ -90,3 +90,30 @@ def record_scatter_workspaces():
         yield seen
     finally:
         field_ops.scatter_workspace = orig
+
+
+@contextlib.contextmanager
+def position_jitter():
+    """torch.randn_like(x) for x [m, 3] -> a unit-variance pseudo-random function of x ITSELF (elementwise torch ops on
+    bit-identical inputs: bit-identical outputs, whatever the row order).  The smoothness jitter of run_cuda
+    (renderer.py:522) is drawn per ROW and the marching waves' slabs arrive in a different order in every run: under this
+    patch every sample keeps its jitter whatever row it lands in, so two runs of a render compare term by term."""
+    import math
+    import torch
+    orig = torch.randn_like
+
+    def fake(x, *a, **k):
+        if x.dim() == 2 and x.shape[-1] == 3 and x.is_floating_point() and not a and not k:
+            p = x.detach().double()
+            f64 = dict(dtype=torch.float64, device=x.device)
+            s = torch.stack([p @ torch.tensor([12.9898, 78.233, 37.719], **f64),
+                             p @ torch.tensor([39.3468, 11.135, 83.155], **f64),
+                             p @ torch.tensor([73.156, 52.235, 9.151], **f64)], -1)
+            u = torch.frac(torch.sin(s) * 43758.5453123).abs()          # [0, 1)
+            return ((u - 0.5) * math.sqrt(12.0)).to(x.dtype)            # unit variance
+        return orig(x, *a, **k)
+    torch.randn_like = fake
+    try:
+        yield
+    finally:
+        torch.randn_like = orig

@@ -1,0 +1,50 @@
+"""CPU: mi3d.grid_ops.GridParameter - the hash table's parameter class (`tinycudann.Encoding.params`).  It IS an
+nn.Parameter (module registration, state_dict key, .to(), deepcopy, optimizers, GradScaler all see a parameter); the one
+thing it adds is that READING `.grad` first completes whatever a backward pass parked on it (grid_ops.DEFER_POINT0,
+mi3d/field_ops.py), and that ASSIGNING `.grad` drops it.  The scatter itself needs the GPU (tests/test_sds_step_gpu.py);
+here the completion hook is observed through a stand-in."""
+import copy
+
+import torch
+
+
+def test_grid_parameter_is_a_parameter_with_a_completing_grad(monkeypatch):
+    import tinycudann as tcnn
+    from mi3d import field_ops, grid_ops
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12,
+                            "base_resolution": 4, "per_level_scale": 1.5})
+    p = enc.params
+    assert isinstance(p, torch.nn.Parameter) and isinstance(p, grid_ops.GridParameter) and p.requires_grad
+    assert list(enc.state_dict().keys()) == ["params"] and [n for n, _ in enc.named_parameters()] == ["params"]
+    # autograd accumulates through the C++ accessor; Python readers go through the property
+    (p * 2).sum().backward()
+    assert torch.equal(p.grad, torch.full_like(p, 2.0))
+    # something parked: the first read completes it (stand-in: adds 1 to the real accumulator), later reads do not
+    calls = []
+
+    def fake_flush(param, key=None):
+        calls.append(len(param.__dict__["_mi3d_pending"]))
+        param.__dict__["_mi3d_pending"].clear()
+        torch.Tensor.grad.__get__(param).add_(1.0)
+    monkeypatch.setattr(field_ops, "flush_pending", fake_flush)
+    p.__dict__["_mi3d_pending"] = [{"key": object()}]
+    assert torch.equal(p.grad, torch.full_like(p, 3.0)) and calls == [1]
+    assert torch.equal(p.grad, torch.full_like(p, 3.0)) and calls == [1]
+    # the readers a training step has: clip_grad_norm_, an optimizer, zero_grad - all complete first
+    p.__dict__["_mi3d_pending"].append({"key": object()})
+    torch.nn.utils.clip_grad_norm_([p], max_norm=1e9)
+    assert calls == [1, 1] and not p.__dict__["_mi3d_pending"]
+    opt = torch.optim.SGD([p], lr=0.5)
+    before = p.detach().clone()
+    p.__dict__["_mi3d_pending"].append({"key": object()})
+    opt.step()
+    assert calls == [1, 1, 1] and torch.allclose(p.detach(), before - 0.5 * 5.0)
+    # assigning .grad replaces what was accumulated - and drops what was parked
+    p.__dict__["_mi3d_pending"].append({"key": object()})
+    p.grad = None
+    assert not p.__dict__["_mi3d_pending"] and p.grad is None and calls == [1, 1, 1]
+    # module plumbing keeps the class
+    enc64 = copy.deepcopy(enc).double()
+    assert isinstance(enc64.params, grid_ops.GridParameter) and enc64.params.dtype == torch.float64
+    enc.load_state_dict(enc.state_dict())
+    assert isinstance(enc.params, grid_ops.GridParameter)

@@ -30,7 +30,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import record_scatter_workspaces
+from conftest import position_jitter, record_scatter_workspaces
 
 pytestmark = pytest.mark.gpu
 
@@ -49,28 +49,6 @@ def ref():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "headline_parity.json"), "w") as f:
             json.dump(REPORT, f, indent=1)
-
-
-@contextlib.contextmanager
-def position_jitter():
-    """torch.randn_like(x) for x [m, 3] -> a unit-variance pseudo-random function of x itself (elementwise torch ops on
-    bit-identical inputs: bit-identical outputs, whatever the row order)."""
-    orig = torch.randn_like
-
-    def fake(x, *a, **k):
-        if x.dim() == 2 and x.shape[-1] == 3 and x.is_floating_point() and not a and not k:
-            p = x.detach().double()
-            s = torch.stack([p @ torch.tensor([12.9898, 78.233, 37.719], dtype=torch.float64, device=x.device),
-                             p @ torch.tensor([39.3468, 11.135, 83.155], dtype=torch.float64, device=x.device),
-                             p @ torch.tensor([73.156, 52.235, 9.151], dtype=torch.float64, device=x.device)], -1)
-            u = torch.frac(torch.sin(s) * 43758.5453123).abs()          # [0, 1)
-            return ((u - 0.5) * math.sqrt(12.0)).to(x.dtype)            # unit variance
-        return orig(x, *a, **k)
-    torch.randn_like = fake
-    try:
-        yield
-    finally:
-        torch.randn_like = orig
 
 
 def _pair(ref, cuda, **opt_kw):
@@ -142,8 +120,10 @@ def _outputs_close(a, b, rtol, atol):
     assert torch.equal(a["mask"], b["mask"])
 
 
-def _run_pair(ref, cuda, name, bitfield, autocast, scale=4.0, seed=31):
-    from mi3d import rays as R, sds_step
+def _run_pair(ref, cuda, name, bitfield, autocast, scale=4.0, seed=31, defer=True):
+    """`defer`: the product parks the first pass's point-0 planes and scatters them with the second pass (the default,
+    grid_ops.DEFER_POINT0: ONE scatter call) or scatters every pass on its own (round 3's behaviour: TWO calls)."""
+    from mi3d import grid_ops, rays as R, sds_step
     theirs, ours, opt = _pair(ref, cuda)
     for m in (theirs, ours):
         sds_step.set_bitfield(m, bitfield)
@@ -152,11 +132,17 @@ def _run_pair(ref, cuda, name, bitfield, autocast, scale=4.0, seed=31):
     inject = (torch.randn(128 * 128, 3, generator=g) * 2e-3).to(cuda)   # the size of an SDS gradient on a 128 x 128 image
     a = _headline_step(theirs, rays, seed, 1024, autocast, scale, inject)
     torch.cuda.empty_cache()
-    with record_scatter_workspaces() as arenas:
-        b = _headline_step(ours, rays, seed, 1024, autocast, scale, inject)
+    was, grid_ops.DEFER_POINT0 = grid_ops.DEFER_POINT0, defer
+    try:
+        with record_scatter_workspaces() as arenas:
+            b = _headline_step(ours, rays, seed, 1024, autocast, scale, inject)
+    finally:
+        grid_ops.DEFER_POINT0 = was
     n = int(ours.step_counter[0, 0])
     assert n == int(theirs.step_counter[0, 0])
-    assert len(arenas) == 2 and all(x > 0 for x in arenas), arenas      # two backward passes, both through the records
+    # both backward passes went through the records: as one call (point 0 of the first pass riding along) or as two
+    assert len(arenas) == (1 if defer else 2) and all(x > 0 for x in arenas), arenas
+    assert not ours.encoder.params.__dict__.get("_mi3d_pending")
     rep = _grad_report(name, theirs, ours)
     rep["samples"], rep["arena_bytes"] = n, arenas
     for k in ("loss_orient", "loss_smooth", "loss"):
@@ -171,21 +157,27 @@ def test_c2_dense_autocast_headline_mode(ref, cuda):
     _outputs_close(a, b, rtol=2e-2, atol=2e-3)          # binary16 resolution through 664 composited samples per ray
     assert abs(rep["loss_orient"][1] - rep["loss_orient"][0]) <= 2e-2 * abs(rep["loss_orient"][0])
     assert abs(rep["loss_smooth"][1] - rep["loss_smooth"][0]) <= 2e-2 * abs(rep["loss_smooth"][0])
-    assert rep["table_max_err_rel"] <= 5e-2, rep
-    assert rep["table_cosine"] >= 0.999, rep
-    assert all(abs(r - 1.0) <= 0.02 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
+    # measured (profiles/headline_parity_r04.json): 9.3e-4 x max, cosine 1.0000, per-level cosines >= 0.99975, per-level
+    # norms within 2e-4; the bounds leave a factor of ~5
+    assert rep["table_max_err_rel"] <= 5e-3, rep
+    assert rep["table_cosine"] >= 0.9999, rep
+    assert min(rep["level_cosine"]) >= 0.998, rep["level_cosine"]
+    assert all(abs(r - 1.0) <= 2e-3 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
     for k, v in rep["mlp"].items():
-        assert v["max_err_rel"] <= 5e-2 and v["cosine"] >= 0.999, (k, v)
+        assert v["max_err_rel"] <= 5e-3 and v["cosine"] >= 0.9999, (k, v)
 
 
-def test_c2_pruned_autocast_headline_mode(ref, cuda):
-    """(b) the same with the pruned occupancy (sphere 0.3: ~2.3 M samples; one scatter slice)."""
-    a, b, rep, n = _run_pair(ref, cuda, "c2_pruned_autocast", 0.3, True)
+@pytest.mark.parametrize("defer", [True, False])
+def test_c2_pruned_autocast_headline_mode(ref, cuda, defer):
+    """(b) the same with the pruned occupancy (sphere 0.3: ~2.3 M samples; one scatter slice), with the first pass's
+    point-0 planes deferred into the second pass's scatter and with every pass scattered on its own."""
+    a, b, rep, n = _run_pair(ref, cuda, "c2_pruned_autocast" + ("" if defer else "_two_scatters"), 0.3, True, defer=defer)
     assert 1_500_000 < n < 3_500_000
     _outputs_close(a, b, rtol=2e-2, atol=2e-3)
-    assert rep["table_max_err_rel"] <= 5e-2, rep
-    assert rep["table_cosine"] >= 0.999, rep
-    assert all(abs(r - 1.0) <= 0.02 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
+    assert rep["table_max_err_rel"] <= 5e-3, rep
+    assert rep["table_cosine"] >= 0.9999, rep
+    assert min(rep["level_cosine"]) >= 0.995, rep["level_cosine"]
+    assert all(abs(r - 1.0) <= 2e-3 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
 
 
 def test_c2_dense_fp32_outputs_1e4(ref, cuda):
@@ -196,9 +188,9 @@ def test_c2_dense_fp32_outputs_1e4(ref, cuda):
     _outputs_close(a, b, rtol=1e-4, atol=1e-6)
     assert abs(rep["loss_orient"][1] - rep["loss_orient"][0]) <= 2e-4 * abs(rep["loss_orient"][0])
     assert abs(rep["loss_smooth"][1] - rep["loss_smooth"][0]) <= 2e-4 * abs(rep["loss_smooth"][0])
-    assert rep["table_max_err_rel"] <= 2e-3, rep
-    assert rep["table_cosine"] >= 0.99999, rep
-    assert all(abs(r - 1.0) <= 1e-3 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
+    assert rep["table_max_err_rel"] <= 1e-3, rep          # measured 2.8e-4 (both routes sit 8e-4 from fp64, test below)
+    assert rep["table_cosine"] >= 0.999999, rep
+    assert all(abs(r - 1.0) <= 1e-4 for r in rep["level_norm_ratio"]), rep["level_norm_ratio"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

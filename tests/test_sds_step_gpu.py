@@ -195,3 +195,158 @@ def test_denoise_clip_branch_full_size_networks(cuda):
     assert torch.isfinite(loss) and not loss.requires_grad and rgb.grad is None
     loss, imgs = g.train_step(g.get_text_embeds(), rgb * 1.0, ref_rgb=ref, ref_text="a toy", clip_model=clip, t=450)
     assert loss == 0 and imgs is None and rgb.grad is not None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the point-0 pass of the two-backward schedule, deferred into the pass that follows it (grid_ops.DEFER_POINT0)
+
+def _two_pass_state(cuda, fp16):
+    from mi3d import rays as R, sds_step
+    opt = sds_step.make_opt(max_steps=128, fp16=fp16)
+    model, _, _ = sds_step.build_training_state(opt, cuda, seed=3, bitfield=0.5)
+    with torch.no_grad():
+        model.encoder.params.uniform_(-0.3, 0.3)
+    rays = R.view_rays(32, 32, device=cuda)
+    inject = (torch.randn(1024, 3, generator=torch.Generator().manual_seed(2)) * 2e-3).to(cuda)
+    return opt, model, rays, inject
+
+
+def _two_passes(model, opt, rays, inject, fp16, between=None, second=True, scale=4.0):
+    """render -> image.backward(inject, retain_graph=True) [point 0 only] -> `between()` -> (scale * loss).backward()."""
+    from conftest import position_jitter
+    from mi3d import sds_step
+    ro, rd, ds = rays
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(11)
+    with position_jitter():
+        with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            out = model.render(ro, rd, depth_scale=ds, bg_color=torch.full((3,), 0.7, device=ro.device), perturb=True,
+                               ambient_ratio=1.0, shading="albedo", force_all_rays=True, dt_gamma=0, max_steps=128)
+            loss = sds_step.regularisers(opt, out, out["weights_sum"].reshape(1, 1, 32, 32))
+        out["image"].backward(inject.view_as(out["image"]), retain_graph=True)
+        mid = between(model) if between is not None else None
+        if second:
+            (scale * loss).backward()
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters()}, mid
+
+
+def _parked(model):
+    return len(model.encoder.params.__dict__.get("_mi3d_pending") or [])
+
+
+def _raw_grad(model):
+    return torch.Tensor.grad.__get__(model.encoder.params)   # what autograd accumulated, without completing anything
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_deferred_point0_scatter_equals_two_scatters(cuda, fp16):
+    """The reference schedule with the first pass's point-0 planes riding along in the second pass's scatter (ONE
+    mi3d_grid_scatter_binned_plus call) against every pass scattered on its own (two calls): the same table gradient up
+    to fp32 rounding of w (a + b) against w a + w b, every other gradient bit-identical; while the planes are parked the
+    raw accumulator holds nothing of the first pass, and nothing stays parked afterwards."""
+    from conftest import record_scatter_workspaces
+    from mi3d import grid_ops
+    opt, model, rays, inject = _two_pass_state(cuda, fp16)
+    grid_ops.DEFER_POINT0 = False
+    try:
+        with record_scatter_workspaces() as calls_two:
+            two, _ = _two_passes(model, opt, rays, inject, fp16)
+    finally:
+        grid_ops.DEFER_POINT0 = True
+    seen = {}
+
+    def between(m):
+        seen["parked"], seen["raw"] = _parked(m), _raw_grad(m)
+    with record_scatter_workspaces() as calls_one:
+        one, _ = _two_passes(model, opt, rays, inject, fp16, between=between)
+    assert len(calls_two) == 2 and len(calls_one) == 1 and all(c > 0 for c in calls_two + calls_one)
+    assert seen["parked"] == 1 and (seen["raw"] is None or float(seen["raw"].abs().max()) == 0.0)
+    assert _parked(model) == 0
+    g2, g1 = two["encoder.params"], one["encoder.params"]
+    scale = float(g2.abs().max())
+    assert scale > 0 and float((g1 - g2).abs().max()) <= 2e-6 * scale
+    assert (g1 != 0).sum() == (g2 != 0).sum()
+    for n in two:
+        if n != "encoder.params":   # MLP weight gradients: float-atomic sums, run-to-run noise
+            assert float((one[n] - two[n]).abs().max()) <= 2e-4 * float(two[n].abs().max()), n
+
+
+def test_reading_grad_completes_a_deferred_scatter(cuda):
+    """Whoever reads encoder.params.grad sees the complete gradient: between the passes (the parked planes are scattered
+    then, and the second pass has nothing left to take along), after a first pass that no second one follows, through a
+    flat all-reduce bucket's view, and not at all after `.grad = None`."""
+    from mi3d import dp, grid_ops
+    opt, model, rays, inject = _two_pass_state(cuda, False)
+    grid_ops.DEFER_POINT0 = False
+    try:
+        two, _ = _two_passes(model, opt, rays, inject, False)
+        first_only, _ = _two_passes(model, opt, rays, inject, False, second=False)
+    finally:
+        grid_ops.DEFER_POINT0 = True
+    tol = lambda ref: 2e-6 * float(ref.abs().max())
+    # (1) a reader between the passes
+    got, mid = _two_passes(model, opt, rays, inject, False,
+                           between=lambda m: (_parked(m), m.encoder.params.grad.detach().clone(), _parked(m)))
+    assert mid[0] == 1 and mid[2] == 0
+    assert float((mid[1] - first_only["encoder.params"]).abs().max()) <= tol(first_only["encoder.params"])
+    assert float((got["encoder.params"] - two["encoder.params"]).abs().max()) <= tol(two["encoder.params"])
+    # (2) no second pass: the first reader gets the first pass's gradient
+    got, _ = _two_passes(model, opt, rays, inject, False, second=False)
+    assert _parked(model) == 0
+    assert float((got["encoder.params"] - first_only["encoder.params"]).abs().max()) <= tol(first_only["encoder.params"])
+    # (3) .grad = None between the passes drops the first pass, parked or not
+    grid_ops.DEFER_POINT0 = False
+    try:
+        want, _ = _two_passes(model, opt, rays, inject, False, between=lambda m: setattr(m.encoder.params, "grad", None))
+    finally:
+        grid_ops.DEFER_POINT0 = True
+    got, _ = _two_passes(model, opt, rays, inject, False, between=lambda m: setattr(m.encoder.params, "grad", None))
+    assert float((got["encoder.params"] - want["encoder.params"]).abs().max()) <= tol(want["encoder.params"])
+    # (4) gradients as views into one flat bucket (mi3d/dp.py): the completed scatter lands in the bucket, in place
+    bucket = dp.FlatGradBucket(model.parameters())
+    from conftest import position_jitter
+    from mi3d import sds_step
+    ro, rd, ds = rays
+    bucket.zero()
+    torch.manual_seed(11)
+    with position_jitter():
+        out = model.render(ro, rd, depth_scale=ds, bg_color=torch.full((3,), 0.7, device=cuda), perturb=True,
+                           ambient_ratio=1.0, shading="albedo", force_all_rays=True, dt_gamma=0, max_steps=128)
+        loss = sds_step.regularisers(opt, out, out["weights_sum"].reshape(1, 1, 32, 32))
+        out["image"].backward(inject.view_as(out["image"]), retain_graph=True)
+        assert _parked(model) == 1
+        (4.0 * loss).backward()
+    bucket.all_reduce_mean()        # (no process group: checks the views, reads every .grad)
+    n_table = model.encoder.params.numel()
+    assert model.encoder.params.grad.data_ptr() == bucket.flat.data_ptr()
+    assert float((bucket.flat[:n_table] - two["encoder.params"]).abs().max()) <= tol(two["encoder.params"])
+    for p in model.parameters():
+        p.grad = None
+
+
+def test_autograd_grad_is_never_deferred(cuda):
+    """torch.autograd.grad hands gradients BACK instead of accumulating them: the node must return the table gradient
+    itself, retain_graph or not - nothing is parked."""
+    from conftest import position_jitter
+    from mi3d import grid_ops
+    opt, model, rays, inject = _two_pass_state(cuda, False)
+    ro, rd, ds = rays
+    outs = []
+    for mode in ("grad", "backward"):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        with position_jitter():
+            out = model.render(ro, rd, depth_scale=ds, bg_color=torch.full((3,), 0.7, device=cuda), perturb=True,
+                               ambient_ratio=1.0, shading="albedo", force_all_rays=True, dt_gamma=0, max_steps=128)
+        if mode == "grad":
+            (g,) = torch.autograd.grad(out["image"], [model.encoder.params], inject.view_as(out["image"]),
+                                       retain_graph=True)
+            assert _parked(model) == 0 and _raw_grad(model) is None
+        else:
+            out["image"].backward(inject.view_as(out["image"]), retain_graph=True)
+            assert _parked(model) == 1
+            g = model.encoder.params.grad.detach().clone()
+        outs.append(g)
+    assert float(outs[0].abs().max()) > 0
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max())
+    assert grid_ops.DEFER_POINT0

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/kbench.json")
     ap.add_argument("--half-planes", action="store_true", help="binary16 feature / gradient planes (the autocast layout)")
     ap.add_argument("--dev", default="", help="tunables set before anything runs, e.g. 10=1,3=2048 (csrc/mi3d_dev.h)")
+    ap.add_argument("--real-census", action="store_true",
+                    help="scatter benchmarks: zero the random gradient pairs independently with the per-level non-zero "
+                         "fractions bench.py's census measured on a real step (regulariser pass + deferred point 0)")
     a = ap.parse_args()
     what = set(a.what.split(","))
     import raymarching
@@ -68,6 +71,20 @@ def main():
     P = 13
     params = torch.empty(12196240, device=dev).uniform_(-1, 1)
     res = {"samples": n, "evals": n * P}
+    # per-level share of non-zero (row, level) gradient pairs of a real C2 step (gpurun_out/r04_1/bench.json: the binary16
+    # underflow pattern at loss scale 2-4; scattered per pair, not clustered per sample: 0.98 of the 64-sample tiles and
+    # 0.73-0.97 of the samples have a non-zero pair on every level); point 0 carries the SDS pass as well: 0.94
+    REAL_NZ = [0.51, 0.75, 0.72, 0.78, 0.74, 0.63, 0.2, 0.63, 0.38, 0.35, 0.6, 0.34, 0.25, 0.35, 0.72, 0.31]
+
+    def gradient_planes(dtype):
+        g = torch.randn(16, P * n, 2, device=dev).to(dtype)
+        if a.real_census:
+            for l in range(16):
+                keep = torch.rand(P * n, device=dev) < REAL_NZ[l]
+                keep[:n] = torch.rand(n, device=dev) < 0.94
+                g[l] *= keep[:, None].to(dtype)
+            res["real_census_nonzero_pair_fraction"] = float((g != 0).any(-1).float().mean())
+        return g
     feats = torch.empty(16, P * n, 2, device=dev, dtype=torch.float16 if a.half_planes else torch.float32)
 
     def encode(out=feats):
@@ -182,16 +199,16 @@ def main():
         res["mlp_bwd_stream_TBps"] = P * n * (128 + 16 + 128) / res["mlp_bwd_ms"] / 1e9
         del dplanes, dh, h
     if "scatter13" in what:  # the 13-point scatter alone, as configured (--dev): for rocprofv3 --kernel-trace --stats
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         torch.manual_seed(11)
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240), a.iters)
         out = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240)
         res["scatter_fp32_P13_checksum"] = int(out.view(torch.int32).to(torch.int64).sum())   # (A/B across builds)
         del g, out
     if "scatter_diag" in what:  # the coarse role alone, with its gather-table atomics switched off (timing only)
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         out = {}
         tune(5, 0x00FF)
         for name, flags in (("all", 0), ("no_sum_adds", 0x100), ("no_cas", 0x200), ("neither", 0x300)):
@@ -220,7 +237,7 @@ def main():
         res["scatter13_dense_fine_role_ms"] = out
         del g
     if "scatter_levels" in what:  # the 13-point scatter per role and per level (dev level mask), dense random gradients
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         masks = {"all": 0xFFFF, "fine_8_15": 0xFF00, "coarse_0_7": 0x00FF}
         masks.update({f"level{l}": 1 << l for l in range(16)})
         out = {}
@@ -232,7 +249,7 @@ def main():
         res["scatter13_dense_ms_by_level_mask"] = out
         del g
     if "scatter_roles" in what:  # each role of the emit alone (dev level mask) against its wave count
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         out = {}
         for name, mk, knob, values in (("fine_8_15", 0xFF00, T_EMIT_FINE, (768, 1024, 1536, 2048, 3072)),
                                         ("coarse_0_7", 0x00FF, T_EMIT_COARSE, (2048, 4096, 8192, 16384))):
@@ -247,7 +264,7 @@ def main():
         del g
     if "scatter" in what:
         step = 2 * 3 ** 0.5 / 1024
-        g = torch.randn(16, P * n, 2, device=dev).to(feats.dtype)
+        g = gradient_planes(feats.dtype)
         res["scatter_fp32_P13_ms"] = timeit(lambda: field_ops.scatter_binned(
             xs, xs2, offs, P0, 1.0, g, cfg, step, 12196240), a.iters)
         g1 = g[:, :n].contiguous()
