@@ -163,7 +163,9 @@ int mi3d_grid_encode_points(const float *x, const float *x2, uint32_t n, const i
  * tied to XCDs so each XCD's L2 only ever holds the table of the level it is gathering from; `step` (the marching
  * step in world units, 0 = unknown) only balances that split, never the result.  The workgroups of an XCD claim their
  * tiles from per-segment counters: 512 bytes of a 64-slot ring in device memory that belongs to the library, zeroed
- * in `stream` before the launch - up to 64 of these calls may be in flight per device, on any streams.
+ * in `stream` before the launch.  Calls on ONE stream may be queued without limit (a slot coming round again is behind
+ * its previous user in stream order); a call that finds its slot last used by ANOTHER stream that has not drained deals
+ * its tiles statically instead of claiming them (same planes, slower) - two live launches never share counters.
  * PLANE ELEMENT TYPE: out_half == 0: fp32 pairs (8 bytes per (level, row)); out_half != 0: binary16 pairs (4 bytes) -
  * for use under torch.autocast(float16) only, where the first nn.Linear rounds its input to binary16 anyway
  * (mi3d_mlp_forward / _backward with half_mode != 0 read them with planes_half != 0: same MLP output, bit for bit,

@@ -832,6 +832,34 @@ struct __attribute__((aligned(16))) RowRecord {
     float a, b, fx;
 };
 constexpr uint32_t kRowEntryBits = 19;
+// ... and with BINARY16 gradient planes (torch.autocast: the pair (dfeature0, dfeature1) is two binary16 numbers) the same
+// pair record takes 12 bytes: the gradient pair travels as its 32 raw bits, the weight w = w_y w_z and the x fraction as
+// 23-bit fixed point (|error| <= 2^-24: the last bit of an fp32 weight near 1; the gradient beside it carries binary16's
+// 2^-11), and the entry as its 13 bits inside the bin - the region a record lies in IS its bin:
+//   word 0 = entry & 8191 | t << 13 | (w_q >> 16) << 18 | (fx_q >> 16) << 25      word 1 = raw binary16 pair
+//   word 2 = (w_q & 0xFFFF) | (fx_q & 0xFFFF) << 16            w_q = round(w 2^23), fx_q = round(fx 2^23), both < 2^23
+// The reduce forms (1 - fx) w (a, b) and fx w (a, b) from them.  fx_q == 0 marks a single, as fx == 0 does above.
+// A quarter less of the arena, of the emit's stores and of the reduce's loads - which is what bounds the reduce (it
+// reads its records at the HBM rate: 72 GB per dense 13-point pass with 16-byte records, profiles/pmc_r03.json).
+struct Row12 { uint32_t w0, w1, w2; };
+constexpr float kFix23 = 8388608.0f, kUnfix23 = 1.0f / 8388608.0f;
+__device__ __forceinline__ uint32_t fix23(float v) {   // v in [0, 1]
+    const uint32_t q = (uint32_t)(v * kFix23 + 0.5f);
+    return q < 8388607u ? q : 8388607u;
+}
+__device__ __forceinline__ Row12 pack_row12(uint32_t e_local, uint32_t t, float w, float fx, uint32_t raw_pair) {
+    const uint32_t wq = fix23(w), fq = fix23(fx);
+    return Row12{e_local | (t << 13) | ((wq >> 16) << 18) | ((fq >> 16) << 25), raw_pair, (wq & 0xFFFFu) | ((fq & 0xFFFFu) << 16)};
+}
+__device__ __forceinline__ void unpack_row12(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t &e_local, uint32_t &t, float &w,
+                                             float &fx, float &dx, float &dy) {
+    e_local = w0 & 8191u;
+    t = (w0 >> 13) & 31u;
+    w = (float)((((w0 >> 18) & 127u) << 16) | (w2 & 0xFFFFu)) * kUnfix23;
+    fx = (float)(((w0 >> 25) << 16) | (w2 >> 16)) * kUnfix23;
+    dx = (float)__builtin_bit_cast(_Float16, (unsigned short)(w1 & 0xFFFFu));
+    dy = (float)__builtin_bit_cast(_Float16, (unsigned short)(w1 >> 16));
+}
 
 struct BinPlan {
     uint32_t level_bin0[MI3D_MAX_LEVELS];   // first bin of each level (bins are numbered level by level)
@@ -841,7 +869,8 @@ struct BinPlan {
     uint32_t level_cnt0[MI3D_MAX_LEVELS];   // first entry of the level in counts[]; inside: [wave][bin]
     uint32_t level_max0[MI3D_MAX_LEVELS];   // first entry of the level in level_max[]; inside: [wave]
     uint64_t total_bytes;
-    uint32_t row_mask;                      // fine fp32 levels stored as 16-byte x-pair records (RowRecord)
+    uint32_t row_mask;                      // fine levels stored as x-pair records (RowRecord, 16 bytes; Row12 with rec12)
+    uint32_t rec12;                         // binary16 gradient planes: the pair records are 12 bytes (Row12)
     uint32_t level_split[MI3D_MAX_LEVELS];  // reduce workgroups that share one bin of the level
     uint32_t level_wg0[MI3D_MAX_LEVELS];    // first reduce workgroup of the level; inside: [bin][split]
     uint32_t n_reduce_wgs;
@@ -863,11 +892,13 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
 // evenly).  Dense levels: bins are spatial, a wave's samples cluster in few of them, and merging thins the records by
 // an unknown factor: the share assumes a quarter of the geometric run length and two-fold imbalance.  A full region is
 // not an error - the overflow goes to the table by atomics.
-inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels) {
+inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels,
+                        bool half_planes = false) {
     const uint32_t fine_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_FINE_WAVES, kEmitWavesMax);
     const uint32_t coarse_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_COARSE_WAVES, 16384);
     BinPlan p{};
     p.n_levels = T.n_levels;
+    p.rec12 = half_planes ? 1u : 0u;
     const uint64_t tiles = (n_slice + kWave - 1) / kWave;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         const GridLevel &L = T.level[l];
@@ -898,7 +929,7 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         p.level_max0[l] = p.total_max;
         p.n_bins += bins;
         p.total_bytes += (uint64_t)p.level_waves[l] * bins * p.level_cap[l] *
-                         (row ? sizeof(RowRecord) : sizeof(BinRecord));
+                         (row ? (p.rec12 ? sizeof(Row12) : sizeof(RowRecord)) : sizeof(BinRecord));
         p.total_bytes = (p.total_bytes + 255u) / 256u * 256u;
         p.total_counts += p.level_waves[l] * bins;
         p.total_max += p.level_waves[l];
@@ -1194,6 +1225,14 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                 uint4 *stage = reinterpret_cast<uint4 *>(sums);
                 uint32_t *hist = keys, *cursor = keys + 64, *gdelta = keys + 128;
                 const uint32_t mask = L.size - 1u;
+                // binary16 planes: 12-byte records (Row12).  The first pass's point-0 pair (extra0) cannot be added into
+                // point 0's raw bits, so it travels as a record of its own: one more "point" at point 0's position
+                Row12 *region12 = reinterpret_cast<Row12 *>(reinterpret_cast<char *>(arena) + plan.level_base[l]) +
+                                  (size_t)gw * level_bins(L) * cap;
+                const bool extra_pt = HP && extra0 != nullptr;
+                const uint32_t Pf = ps.P + (extra_pt ? 1u : 0u);
+                uint32_t ex_raw = 0u;
+                if (extra_pt) ex_raw = reinterpret_cast<const uint32_t *>(extra0)[(size_t)l * n_rows + (valid ? s : s_end - 1u)];
                 auto to_table = [&](uint32_t e, float va, float vb) __attribute__((always_inline)) {  // straight to the table (float atomics)
                     float *dst = grad_table + ((size_t)L.offset + e) * 2;
                     unsafeAtomicAdd(dst, va); unsafeAtomicAdd(dst + 1, vb);
@@ -1203,6 +1242,13 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     const uint32_t slot = atomicAdd(&fill_l[bin], 1u);
                     if (slot < cap) region0[__umul24(bin, cap) + slot] = RowRecord{e, va, vb, 0.f};
                     else to_table(e, va, vb);
+                };
+                // (binary16 planes: the single carries its whole weight wgt = (1 - fx) w or fx w, and fx_q = 0)
+                auto put_single12 = [&](uint32_t e, float wgt, uint32_t raw, float dx, float dy) __attribute__((always_inline)) {
+                    const uint32_t bin = e >> kBinShift;
+                    const uint32_t slot = atomicAdd(&fill_l[bin], 1u);
+                    if (slot < cap) region12[__umul24(bin, cap) + slot] = pack_row12(e & (kBinEntries - 1u), 0u, wgt, 0.f, raw);
+                    else to_table(e, wgt * dx, wgt * dy);
                 };
                 // the four (y, z) corner pairs of a cell: e0 = entry of the x corner, e1 = of the x + 1 corner
                 auto pair_entries = [&](uint32_t cx, uint32_t cy, uint32_t cz, uint32_t j, uint32_t &e0, uint32_t &e1) __attribute__((always_inline)) {
@@ -1220,7 +1266,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     return (e0 >> kBinShift) == (e1 >> kBinShift) && (L.hashed || e1 == e0 + 1u);
                 };
                 hist[lane] = 0u;
-                for (uint32_t p0 = 0; p0 < ps.P; p0 += kChunkPts) {
+                for (uint32_t p0 = 0; p0 < Pf; p0 += kChunkPts) {
                     // (per chunk point: its x cell and fractions, its gradient pair, the four x-corner entries e0 and which of
                     // them leave a pair record - kept for pass 2, which used to derive them a second time: with the
                     // hash's two 32-bit multiplies per corner pair that was a third of the role's 820 VALU instructions
@@ -1242,13 +1288,14 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
 #pragma unroll
                     for (uint32_t c = 0; c < kChunkPts; ++c) {
                         const uint32_t p = p0 + c;  // uniform
+                        if (extra_pt && p == ps.P) craw0[c] = ex_raw;   // the extra "point": point 0's position, the first pass's pair
                         const uint32_t r0 = craw0[c], r1 = craw1[c];
                         float2 d = HP
                             ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                           (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))
                             : make_float2(__uint_as_float(r0), __uint_as_float(r1));
-                        if (p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform)
-                        const bool has = valid && p < ps.P && (d.x != 0.f || d.y != 0.f);
+                        if (!HP && p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform; fp32 planes: summed in place)
+                        const bool has = valid && p < Pf && (d.x != 0.f || d.y != 0.f);
                         const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
                         float q[3];
                         point_of(ps, base, p < ps.P ? p : 0u, q);
@@ -1288,7 +1335,8 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                                     // reference's atomicAdd would have put the inf / NaN
                                     const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
                                     const float a = w * d.x, b = w * d.y;
-                                    if (finite) { put_single(e0, gx * a, gx * b); put_single(e1, cfx[c] * a, cfx[c] * b); }
+                                    if (finite && HP) { put_single12(e0, gx * w, r0, d.x, d.y); put_single12(e1, cfx[c] * w, r0, d.x, d.y); }
+                                    else if (finite) { put_single(e0, gx * a, gx * b); put_single(e1, cfx[c] * a, cfx[c] * b); }
                                     else { to_table(e0, gx * a, gx * b); to_table(e1, cfx[c] * a, cfx[c] * b); }
                                 }
                             }
@@ -1335,6 +1383,10 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                                     const uint32_t e0 = ce0[c][j];
                                     const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
                                     const uint32_t pos = atomicAdd(&cursor[e0 >> kBinShift], 1u);
+                                    if (HP) {   // Row12 + the bin in the fourth word (the staging slot stays 16 bytes: one LDS write)
+                                        const Row12 r = pack_row12(e0 & (kBinEntries - 1u), t, w, cfx[c], craw0[c]);
+                                        stage[pos] = make_uint4(r.w0, r.w1, r.w2, e0 >> kBinShift);
+                                    } else
                                     stage[pos] = make_uint4(e0 | (t << kRowEntryBits), __float_as_uint(w * cd0[c]),
                                                             __float_as_uint(w * cd1[c]), __float_as_uint(cfx[c]));
                                 }
@@ -1348,6 +1400,24 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     // the sorted records leave: consecutive lanes, consecutive slots of a region
                     for (uint32_t i = lane; i < total; i += kWave) {
                         const uint4 rec = stage[i];
+                        if (HP) {
+                            const uint32_t bin = rec.w, slot = i + gdelta[bin];
+                            if (slot < cap) {
+#ifdef MI3D_DEV  // tools build: 0x800 = the records are sorted but not stored (timing only)
+                                if (!(fine_level_major & 0x800u))
+#endif
+                                region12[__umul24(bin, cap) + slot] = Row12{rec.x, rec.y, rec.z};
+                            } else {  // region full: straight to the table
+                                uint32_t el, tt;
+                                float w, fx, dx, dy;
+                                unpack_row12(rec.x, rec.y, rec.z, el, tt, w, fx, dx, dy);
+                                const uint32_t e0 = (bin << kBinShift) | el;
+                                const uint32_t e1 = L.hashed ? (e0 ^ (((1u << tt) - 1u) & mask)) : e0 + 1u;
+                                to_table(e0, (1.0f - fx) * (w * dx), (1.0f - fx) * (w * dy));
+                                if (fx != 0.f) to_table(e1, fx * (w * dx), fx * (w * dy));
+                            }
+                            continue;
+                        }
                         const uint32_t e0 = rec.x & ((1u << kRowEntryBits) - 1u), bin = e0 >> kBinShift;
                         const uint32_t slot = i + gdelta[bin];
                         if (slot < cap) {
@@ -1579,7 +1649,34 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
         uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
         cnt = cnt < cap ? cnt : cap;
-        if (row) {
+        if (row && plan.rec12) {   // binary16 gradient planes: 12-byte pair records
+            const Row12 *src = reinterpret_cast<const Row12 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
+            const bool hashed = T.level[lvl].hashed;
+            for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
+                Row12 rec[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    const uint32_t i = i0 + u * kWave + lane;
+                    rec[u] = i < cnt ? src[i] : Row12{0u, 0u, 0u};
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    if (i0 + u * kWave + lane < cnt) {
+                        uint32_t l0, t;
+                        float w, fx, dx, dy;
+                        unpack_row12(rec[u].w0, rec[u].w1, rec[u].w2, l0, t, w, fx, dx, dy);
+                        const float a = w * dx, bb = w * dy, gx = 1.0f - fx;
+                        atomicAdd(&acc[l0], fixed_point((gx * a) * scale));
+                        atomicAdd(&acc[kBinEntries + l0], fixed_point((gx * bb) * scale));
+                        if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
+                            const uint32_t l1 = hashed ? (l0 ^ ((1u << t) - 1u)) & (kBinEntries - 1u) : l0 + 1u;
+                            atomicAdd(&acc[l1], fixed_point((fx * a) * scale));
+                            atomicAdd(&acc[kBinEntries + l1], fixed_point((fx * bb) * scale));
+                        }
+                    }
+                }
+            }
+        } else if (row) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
             const GridLevel &L = T.level[lvl];
             for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
@@ -1770,13 +1867,34 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     uint32_t *next = nullptr;
     if (MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0) {
+        // One counter slot per launch, a ring of 64, zeroed in-stream right before the kernel.  Launches on ONE stream
+        // are ordered, so a slot coming round again is free by then.  A slot last used on ANOTHER stream may still be
+        // read by that stream's kernel (the host can run 64 launches ahead of the GPU): such a launch leaves the slot
+        // alone and deals its tiles statically (next == nullptr: the round-2 order, same planes, a few ms slower) -
+        // never two live launches on one set of counters.
         static std::atomic<uint32_t> launches{0};
+        static void *const kUnused = reinterpret_cast<void *>(~(uintptr_t)0);
+        static std::atomic<void *> *const slot_stream = [] {
+            static std::atomic<void *> a[kPlanSlots];
+            for (auto &sref : a) sref.store(kUnused);
+            return a;
+        }();
         uint32_t *base = nullptr;
         hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_encode_next));
         if (e != hipSuccess) return (int)e;
-        next = base + (size_t)(launches.fetch_add(1u) % kPlanSlots) * kXcds * kMaxSegs;
-        e = hipMemsetAsync(next, 0, sizeof(uint32_t) * kXcds * kMaxSegs, st);
-        if (e != hipSuccess) return (int)e;
+        const uint32_t slot = launches.fetch_add(1u) % kPlanSlots;
+        void *const mine = reinterpret_cast<void *>(st);
+        void *const prev = slot_stream[slot].load();
+        // (a slot whose other stream has drained is free again: hipStreamQuery does not block)
+        const bool free_now = prev == kUnused || prev == mine ||
+                              hipStreamQuery(reinterpret_cast<hipStream_t>(prev)) == hipSuccess;
+        if (!free_now) (void)hipGetLastError();   // hipErrorNotReady is not a failure of this call
+        if (free_now) {
+            slot_stream[slot].store(mine);
+            next = base + (size_t)slot * kXcds * kMaxSegs;
+            e = hipMemsetAsync(next, 0, sizeof(uint32_t) * kXcds * kMaxSegs, st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     if ((variant & 3) == 3)
         hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
@@ -1845,10 +1963,11 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
 
     // the slice: the largest sample count (halving from n) whose record arena fits the workspace
     uint64_t n_slice = n;
-    BinPlan plan = plan_for(T, n_slice, P, step01, merge_levels);
+    const uint32_t P_rec = P + ((extra0 != nullptr && dout_half) ? 1u : 0u);   // (binary16: the extra pair is a record of its own)
+    BinPlan plan = plan_for(T, n_slice, P_rec, step01, merge_levels, dout_half != 0);
     while (n_slice > kWave && bin_workspace_bytes(plan) > workspace_bytes) {
         n_slice = (n_slice + 1) / 2;
-        plan = plan_for(T, n_slice, P, step01, merge_levels);
+        plan = plan_for(T, n_slice, P_rec, step01, merge_levels, dout_half != 0);
     }
     if (workspace == nullptr || bin_workspace_bytes(plan) > workspace_bytes) {
         // no usable workspace: the atomic kernels, with private copies of the table against same-line serialisation

@@ -22,13 +22,43 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Stock-PyTorch knobs of the diffusion half, each switchable for an A/B (tools/sd_knobs.py):
+#   GN_SPLIT_STATS  F.group_norm's forward statistics kernel (at::native RowwiseMomentsCUDAKernel) runs ONE workgroup per
+#                   (sample, group): 32 workgroups on a 256-CU chip for the batch-1 VAE encoder - 0.88 ms for one
+#                   512 x 512 x 128 activation, 150 GB/s; 6.7 ms of a step (profiles/kernel_stats_r04_bench_steps.csv).
+#                   The same normalisation through torch.var_mean (a multi-workgroup reduction) and ONE fused
+#                   multiply-add pass, in fp32 as autocast runs group_norm; autograd differentiates it.
+#   VAE_HALF_CACHE  under autocast every fp32 conv weight of the frozen VAE encoder is cast to binary16 on every call
+#                   (autocast only caches casts of tensors that require grad): keep a binary16 copy and use it whenever
+#                   autocast(float16) is on - the same rounded weights, no casts.
+GN_SPLIT_STATS = True
+VAE_HALF_CACHE = True
+
+
+class GroupNorm(nn.GroupNorm):
+    def forward(self, x):
+        B, C = x.shape[0], x.shape[1]
+        if not (GN_SPLIT_STATS and x.is_cuda and B * self.num_groups <= 256 and x[0].numel() // self.num_groups >= 65536):
+            return super().forward(x)
+        out_dtype = torch.float32 if torch.is_autocast_enabled("cuda") else x.dtype   # autocast: group_norm runs in fp32
+        with torch.autocast("cuda", enabled=False):
+            xf = x.float()
+            var, mean = torch.var_mean(xf.reshape(B, self.num_groups, -1), dim=-1, unbiased=False)     # [B, G]
+            rstd = torch.rsqrt(var + self.eps)
+            per = C // self.num_groups
+            a = rstd.repeat_interleave(per, 1) * self.weight.float()                                   # [B, C]
+            b = self.bias.float() - mean.repeat_interleave(per, 1) * a
+            shape = (B, C) + (1,) * (x.dim() - 2)
+            return torch.addcmul(b.view(shape), xf, a.view(shape)).to(out_dtype)
+
+
 class ResBlock(nn.Module):
     def __init__(self, cin, cout, temb=None, eps=1e-5):
         super().__init__()
-        self.norm1 = nn.GroupNorm(32, cin, eps=eps)
+        self.norm1 = GroupNorm(32, cin, eps=eps)
         self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
         self.time = nn.Linear(temb, cout) if temb else None
-        self.norm2 = nn.GroupNorm(32, cout, eps=eps)
+        self.norm2 = GroupNorm(32, cout, eps=eps)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
@@ -78,7 +108,7 @@ class TransformerBlock(nn.Module):
 class SpatialTransformer(nn.Module):
     def __init__(self, ch, ctx_dim, head_dim=64):
         super().__init__()
-        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.norm = GroupNorm(32, ch, eps=1e-6)
         self.proj_in = nn.Linear(ch, ch)
         self.block = TransformerBlock(ch, ctx_dim, ch // head_dim)
         self.proj_out = nn.Linear(ch, ch)
@@ -117,7 +147,7 @@ class UNetSD2(nn.Module):
                 if i == layers and lvl > 0:
                     blk.append(nn.Conv2d(c, c, 3, padding=1))  # after nearest x2 upsample
                 self.up.append(nn.ModuleList(blk))
-        self.norm_out, self.conv_out = nn.GroupNorm(32, c), nn.Conv2d(c, 4, 3, padding=1)
+        self.norm_out, self.conv_out = GroupNorm(32, c), nn.Conv2d(c, 4, 3, padding=1)
 
     def forward(self, x, t, encoder_hidden_states):
         half = self.ch0 // 2
@@ -156,8 +186,8 @@ class VAEEncoderSD(nn.Module):
                 blocks.append(nn.Conv2d(c, c, 3, stride=2, padding=0))
         self.blocks = nn.ModuleList(blocks)
         self.mid1, self.mid2 = ResBlock(c, c, None, eps=1e-6), ResBlock(c, c, None, eps=1e-6)
-        self.mid_norm, self.mid_attn = nn.GroupNorm(32, c, eps=1e-6), Attention(c, c, 1)
-        self.norm_out, self.conv_out = nn.GroupNorm(32, c, eps=1e-6), nn.Conv2d(c, 8, 3, padding=1)
+        self.mid_norm, self.mid_attn = GroupNorm(32, c, eps=1e-6), Attention(c, c, 1)
+        self.norm_out, self.conv_out = GroupNorm(32, c, eps=1e-6), nn.Conv2d(c, 8, 3, padding=1)
         self.quant_conv = nn.Conv2d(8, 8, 1)
 
     def forward(self, x):
@@ -184,7 +214,7 @@ class VAEDecoderSD(nn.Module):
         c = ch[0]
         self.conv_in = nn.Conv2d(4, c, 3, padding=1)
         self.mid1, self.mid2 = ResBlock(c, c, None, eps=1e-6), ResBlock(c, c, None, eps=1e-6)
-        self.mid_norm, self.mid_attn = nn.GroupNorm(32, c, eps=1e-6), Attention(c, c, 1)
+        self.mid_norm, self.mid_attn = GroupNorm(32, c, eps=1e-6), Attention(c, c, 1)
         blocks = []
         for lvl, co in enumerate(ch):
             for _ in range(layers):
@@ -193,7 +223,7 @@ class VAEDecoderSD(nn.Module):
             if lvl < len(ch) - 1:
                 blocks.append(nn.Conv2d(c, c, 3, padding=1))  # after nearest x2
         self.blocks = nn.ModuleList(blocks)
-        self.norm_out, self.conv_out = nn.GroupNorm(32, c, eps=1e-6), nn.Conv2d(c, 3, 3, padding=1)
+        self.norm_out, self.conv_out = GroupNorm(32, c, eps=1e-6), nn.Conv2d(c, 3, 3, padding=1)
 
     def forward(self, z):
         h = self.mid1(self.conv_in(self.post_quant_conv(z)))
@@ -310,8 +340,22 @@ class StableDiffusionStandIn(nn.Module):
         g = torch.Generator(device="cpu").manual_seed(1)
         return torch.randn(2, 77, 1024, generator=g).to(self.device)
 
+    def _vae_encoder_for(self, x):
+        """The encoder to run: its binary16 copy under autocast(float16) on the GPU (VAE_HALF_CACHE), else the fp32 one."""
+        if not (VAE_HALF_CACHE and x.is_cuda and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.float16):
+            return self.vae_encoder
+        half = self.__dict__.get("_vae_encoder_half")
+        if half is None:
+            import copy
+            half = copy.deepcopy(self.vae_encoder).half()
+            for p in half.parameters():
+                p.requires_grad_(False)
+            self.__dict__["_vae_encoder_half"] = half      # (not a registered sub-module: state_dict stays the fp32 model's)
+        return half
+
     def encode_imgs(self, imgs):
-        moments = self.vae_encoder(2 * imgs - 1)
+        moments = self._vae_encoder_for(imgs)(2 * imgs - 1)
         mean, logvar = moments.chunk(2, 1)
         std = torch.exp(0.5 * logvar.clamp(-30, 20))
         return (mean + std * torch.randn_like(mean)) * 0.18215
@@ -431,16 +475,32 @@ class StableDiffusionStandIn(nn.Module):
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     gy = self.unet(gx, gt, encoder_hidden_states=gc)
                 self._graph = (key, g, gx, gt, gc, gy)
-            except Exception:  # noqa: BLE001 - capture is an optimisation, never a requirement
+            except RuntimeError as e:
+                # capture is an optimisation, never a requirement - but only a CAPTURE problem may switch it off, and not
+                # silently: anything else (a shape or dtype bug, an out-of-memory) would hide behind the eager path
+                msg = str(e)
+                if isinstance(e, torch.cuda.OutOfMemoryError) or not any(
+                        k in msg.lower() for k in ("captur", "graph", "stream")):
+                    raise
+                import warnings
+                warnings.warn(f"U-Net hipGraph capture unavailable, running eagerly from now on: {msg.splitlines()[0]}")
                 self.graph_unet = False
                 torch.cuda.synchronize(x.device)
                 return self.unet(x, t, encoder_hidden_states=ctx)
         _, g, gx, gt, gc, gy = self._graph
+        cur = torch.cuda.current_stream(x.device)
+        # the graph's input / output buffers are shared by every caller: a replay queued on ANOTHER stream (the side
+        # stream of sds_gradient_async) must have finished with them before this stream overwrites its inputs
+        done = self.__dict__.get("_graph_done")
+        if done is not None:
+            cur.wait_event(done)
         gx.copy_(x)
         gt.copy_(t)
         gc.copy_(ctx)
         g.replay()
-        return gy.clone()   # the graph's output buffer is overwritten by the next replay
+        out = gy.clone()   # the graph's output buffer is overwritten by the next replay
+        self.__dict__["_graph_done"] = cur.record_event()
+        return out
 
     def sds_gradient(self, text_embeddings, pred_rgb, guidance_scale=10, t=None):
         """Returns (latents [1,4,64,64] with graph, grad [1,4,64,64]) - sd.py:124-151,163-170."""

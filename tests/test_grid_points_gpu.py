@@ -166,6 +166,56 @@ def test_binned_scatter_matches_pointwise_oracle(cuda, oracle, second, workspace
     assert np.mean((g != 0) != (ref != 0)) < 1e-6
 
 
+@pytest.mark.parametrize("workspace", ["auto", "tiny", "none"])
+@pytest.mark.parametrize("half", [False, True])
+def test_binned_scatter_with_a_second_pair_for_point_0(cuda, oracle, half, workspace):
+    """mi3d_grid_scatter_binned_plus: the 13-point scatter that also takes the point-0 planes of an earlier backward pass
+    (`extra0`) == the oracle's per-point backward passes + one more pass over point 0 with the extra pair.  fp32 planes
+    (16-byte pair records, the two point-0 pairs summed in fp32) and binary16 planes (12-byte records: the pair as raw
+    bits, weight and x fraction as 23-bit fixed point, the extra pair as a record of its own); one slice, several slices,
+    and the all-atomic fallback (which scatters the extra pair in a pass of its own)."""
+    import ctypes
+    from mi3d import _lib, field_ops, grid_ops
+    rng = np.random.default_rng(19)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=cfg.n_levels, base_resolution=cfg.base_resolution, per_level_scale=cfg.per_level_scale,
+                log2_hashmap_size=cfg.log2_hashmap_size)
+    n = 3000
+    x = _ray_like_points(rng, n, 1.0)
+    x[:8] = 1.0
+    x2 = (x + rng.normal(size=x.shape).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    P = offs.shape[0]
+    dt = np.float16 if half else np.float32
+    dout = rng.normal(size=(n, P, 16, 2)).astype(dt)
+    dout[100:140] = 0
+    dout[:, 2, 2] = 0
+    extra = rng.normal(size=(n, 16, 2)).astype(dt)
+    extra[50:120] = 0
+    extra[200:260, 12] = -dout[200:260, 0, 12]          # the two point-0 pairs cancel exactly on one fine level
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))   # [L][p*n + s][2]
+    eplanes = np.ascontiguousarray(extra.transpose(1, 0, 2))                          # [L][n][2]
+    ws = {"auto": None, "none": 0}.get(workspace, "tiny")
+    if ws == "tiny":
+        ws = int(_lib.lib().mi3d_grid_scatter_binned_workspace(n // 3, P, 1.0, 0.0034, 16, 16, cfg.per_level_scale, 19))
+    with record_scatter_workspaces() as arenas:
+        g = field_ops.scatter_binned(T(x, cuda), T(x2, cuda), offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params,
+                                     workspace_bytes=ws, extra0=T(eplanes, cuda)).cpu().numpy()
+    assert (arenas == []) if workspace == "none" else (len(arenas) == 1 and arenas[0] > 0)
+    ref = np.zeros(cfg.n_params, np.float64)
+    pts = _points(x, x2, offs, P0, 1.0)
+    for p, q in enumerate(pts):
+        h01 = ((q + np.float32(1.0)) / np.float32(2.0)).astype(np.float32)
+        ref += oracle.hashgrid_backward(h01, dout[:, p].astype(np.float32).reshape(n, 32), cfg)
+    ref += oracle.hashgrid_backward(((pts[0] + np.float32(1.0)) / np.float32(2.0)).astype(np.float32),
+                                    extra.astype(np.float32).reshape(n, 32), cfg)
+    scale = np.abs(ref).max()
+    assert np.abs(g - ref).max() <= 2e-5 * scale + 1e-6
+    with pytest.raises(_lib.Mi3dError):     # the extra planes must match the main ones in type
+        field_ops.scatter_binned(T(x, cuda), T(x2, cuda), offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params,
+                                 extra0=T(eplanes.astype(np.float16 if not half else np.float32), cuda))
+
+
 def test_field_stencil_node_equals_layer_composition(cuda, oracle):
     """The fused autograd node (encode + MLP, binned scatter) against the per-layer composition on the same inputs."""
     from mi3d import field_ops, grid_ops, mlp_ops
