@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/mi3d.h"
 #include "mi3d_dev.h"
@@ -283,6 +284,16 @@ __device__ __forceinline__ void corner_entries4(const GridLevel &L, const LevelF
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) e[j] = grid_entry(L, cx + (j & 1u), cy + (j >> 1), cz + zb);
+}
+
+// one corner's entry by the same routes
+__device__ __forceinline__ uint32_t corner_entry1(const GridLevel &L, const LevelFast &F, uint32_t x, uint32_t y, uint32_t z) {
+    if (F.kind == kHashPow2) return (x ^ (y * kPrimeY) ^ (z * kPrimeZ)) & F.last;
+    if (F.kind == kDense3) {
+        const uint32_t a = x + __umul24(y, L.res) + __umul24(z, F.res2), size = F.last + 1u;
+        return min(a, a - size);
+    }
+    return grid_entry(L, x, y, z);
 }
 
 // returns false if this wave has to take the general path for the point (kDense3: a lane in the box's last cells)
@@ -1057,6 +1068,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
     const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
     const bool level_major = !role_b && (fine_level_major & 1u);
+#ifdef MI3D_DEV  // tools build: 0x10000 = the coarse role's shared-face pass off (A/B against round 3's pair passes)
+    const bool face_on = !(fine_level_major & 0x10000u);
+#else
+    constexpr bool face_on = true;
+#endif
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
     float b00 = 0.f, b01 = 0.f, b02 = 0.f, b10 = 0.f, b11 = 0.f, b12 = 0.f;  // the tile's positions
@@ -1206,6 +1222,62 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         }
                     }
                 }
+            };
+            // four given entries into the gather table (the second half of what gather8 does per batch)
+            auto gather4 = [&](const uint32_t (&e)[4], const float (&g0)[4], const float (&g1)[4]) __attribute__((always_inline)) {
+                uint32_t slot[4], old[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) slot[j] = (e[j] * 2654435761u) >> (32 - 9);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j)
+                    old[j] = (g0[j] != 0.f || g1[j] != 0.f) ? atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]) : e[j];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (!(g0[j] != 0.f || g1[j] != 0.f)) continue;
+                    bool placed = old[j] == kMergeEmpty || old[j] == e[j];
+                    for (uint32_t tries = 1; !placed && tries < kMergeProbes; ++tries) {
+                        slot[j] = (slot[j] + 1u) & (kMergeSlots - 1u);
+                        const uint32_t o = atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]);
+                        placed = o == kMergeEmpty || o == e[j];
+                    }
+                    if (placed) {
+                        atomicAdd(&sums[2 * slot[j]], fixed_point(g0[j] * merge_scale));
+                        atomicAdd(&sums[2 * slot[j] + 1], fixed_point(g1[j] * merge_scale));
+                    } else {
+                        emit_record(plan, L, l, gw, e[j], g0[j], g1[j], fill, arena, grad_table, lmax);
+                    }
+                }
+            };
+            // A +eps / -eps neighbour pair along AXIS whose point left the base cell sits in the cell NEXT to it: the four
+            // corners on the face between the two cells ARE corners of the base cell - those contributions join the group's
+            // register sums - and only the four corners of the far face go through the gather table: 12 LDS atomics per
+            // pair pass instead of 24 (a lane cannot leave on both sides, so one far face per lane; the LDS atomics are 56 %
+            // of this role, profiles/kbench_r03_scatter_diag.json).  fa: the lane's + point moved to base + 1 along AXIS,
+            // fb: its - point moved to base - 1; everything else equal to the base cell.
+            auto face_pass = [&](auto axis_tag, bool fa, bool fb, const float (&a0)[8], const float (&a1)[8],
+                                 const float (&b0)[8], const float (&b1)[8]) __attribute__((always_inline)) {
+                constexpr uint32_t AXIS = decltype(axis_tag)::value, m = 1u << AXIS;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    if (!(k & m)) { acc0[k | m] += fa ? a0[k] : 0.f; acc1[k | m] += fa ? a1[k] : 0.f; }   // +: its near face
+                    else { acc0[k & ~m] += fb ? b0[k] : 0.f; acc1[k & ~m] += fb ? b1[k] : 0.f; }          // -: its near face
+                }
+                uint32_t e[4];
+                float f0[4], f1[4];
+                const uint32_t far_c = (AXIS == 0 ? bx : (AXIS == 1 ? by : bz)) + (fa ? 2u : 0xFFFFFFFFu);   // base + 2 / base - 1
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t lo = j & 1u, hi = j >> 1;   // the two other axes' bits, in x < y < z order
+                    const uint32_t k1 = AXIS == 0 ? (1u | lo << 1 | hi << 2) : (AXIS == 1 ? (lo | 2u | hi << 2) : (lo | hi << 1 | 4u));
+                    const uint32_t k0 = k1 & ~m;
+                    f0[j] = fa ? a0[k1] : (fb ? b0[k0] : 0.f);
+                    f1[j] = fa ? a1[k1] : (fb ? b1[k0] : 0.f);
+                    const uint32_t x = AXIS == 0 ? far_c : bx + lo;
+                    const uint32_t y = AXIS == 1 ? far_c : by + (AXIS == 0 ? lo : hi);
+                    const uint32_t z = AXIS == 2 ? far_c : bz + hi;
+                    e[j] = corner_entry1(L, LF, x, y, z);
+                }
+                gather4(e, f0, f1);
             };
             auto flush_group = [&]() __attribute__((always_inline)) {
                 if (acc_any) {
@@ -1502,7 +1574,32 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                             acc1[k] += (same_a ? a1[k] : 0.f) + (same_b ? b1[k] : 0.f);
                         }
                     }
-                    const bool ex_a = has_a && !same_a, ex_b = has_b && !same_b;
+                    bool ex_a = has_a && !same_a, ex_b = has_b && !same_b;
+                    // the pair is (+eps, -eps) along one axis (the reference's stencil, network_tcnn.py:117-122: +x -x +y -y
+                    // +z -z): a point that left the base cell is in the cell next to it - see face_pass
+                    int axis = -1;
+                    if (paired && ps.mode == 1 && face_on) {
+                        const float4 oa = ps.offs[p], ob = ps.offs[p + 1u];
+                        const int nz = (oa.x != 0.f) + (oa.y != 0.f) + (oa.z != 0.f);
+                        if (nz == 1 && ob.x == -oa.x && ob.y == -oa.y && ob.z == -oa.z && oa.x + oa.y + oa.z > 0.f)
+                            axis = oa.x != 0.f ? 0 : (oa.y != 0.f ? 1 : 2);
+                    }
+                    if (axis >= 0 && __ballot(ex_a || ex_b) != 0ull) {
+                        const uint32_t ca = axis == 0 ? ax : (axis == 1 ? ay : az), cb = axis == 0 ? cx2 : (axis == 1 ? cy2 : cz2);
+                        const uint32_t cbase = axis == 0 ? bx : (axis == 1 ? by : bz);
+                        const bool rest_a = (axis == 0 || ax == bx) && (axis == 1 || ay == by) && (axis == 2 || az == bz);
+                        const bool rest_b = (axis == 0 || cx2 == bx) && (axis == 1 || cy2 == by) && (axis == 2 || cz2 == bz);
+                        const bool fa = ex_a && rest_a && ca == cbase + 1u;
+                        const bool fb = ex_b && rest_b && cb + 1u == cbase && !fa;   // (one far face per lane and pass)
+                        if (__ballot(fa || fb) != 0ull) {
+                            acc_any = true;
+                            if (axis == 0) face_pass(std::integral_constant<uint32_t, 0>{}, fa, fb, a0, a1, b0, b1);
+                            else if (axis == 1) face_pass(std::integral_constant<uint32_t, 1>{}, fa, fb, a0, a1, b0, b1);
+                            else face_pass(std::integral_constant<uint32_t, 2>{}, fa, fb, a0, a1, b0, b1);
+                            ex_a = ex_a && !fa;
+                            ex_b = ex_b && !fb;
+                        }
+                    }
                     if (__ballot(ex_a || ex_b) != 0ull) {
 #pragma unroll
                         for (uint32_t k = 0; k < 8; ++k) {  // in place (registers): zeros are skipped by gather8

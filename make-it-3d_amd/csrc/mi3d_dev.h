@@ -33,6 +33,7 @@ enum : int {
                                    //   0x1000  fine role: stop a chunk after pass 1 (cells, entries, histogram)
                                    //   0x2000  fine role: stop a chunk after the bin prefix sum
                                    //   0x4000  fine role: stop a chunk after the records are staged
+                                   //  0x10000  coarse role: shared-face pass off (round 3's pair passes; same sums)
     MI3D_T_MLP_FWD_WGS_PER_CU = 11,       // MLP forward: workgroups per CU
     MI3D_T_ENCODE_COARSE_WGS_PER_CU = 12, // gather: workgroups per CU on the coarse segments
     MI3D_T_MARCH_RPW_MIN = 13,     // march: smallest rays per wave the launch may choose

@@ -31,8 +31,11 @@ import torch.nn.functional as F
 #   VAE_HALF_CACHE  under autocast every fp32 conv weight of the frozen VAE encoder is cast to binary16 on every call
 #                   (autocast only caches casts of tensors that require grad): keep a binary16 copy and use it whenever
 #                   autocast(float16) is on - the same rounded weights, no casts.
+# Measured (tools/sd_knobs.py, profiles/sd_knobs_r04.json; one box, 10 calls each): GN_SPLIT_STATS 34.1 -> 32.2 ms per
+# guidance call (VAE encode 11.4 -> 9.5, backward unchanged) - ON; VAE_HALF_CACHE 34.07 -> 34.25 / 32.22 -> 32.13, i.e.
+# nothing (the casts are 60 small kernels on otherwise idle CUs) - OFF, the encoder keeps the reference's fp32 weights.
 GN_SPLIT_STATS = True
-VAE_HALF_CACHE = True
+VAE_HALF_CACHE = False
 
 
 class _SplitStatsGroupNorm(torch.autograd.Function):

@@ -169,3 +169,54 @@ def test_refine_train_step_draws_its_own_timestep(cuda):
     assert np.isfinite(base) and np.isfinite(with_clip)
     for _ in range(6):
         assert torch.isfinite(refine.refine_train_step(*args, clip_model=clip, ref_rgb=ref_rgb, ref_text="a toy"))
+
+
+def test_refine_train_step_with_the_trainer_level_terms(cuda):
+    """nerf/utils.py:872-884 as the trainer issues them: the front view's masked L1 against the reference image, the novel
+    view's guidance step + 10 x CLIP image-image + contextual (VGG19 relu5_4) terms - both change the point colours, the
+    learned features and the U-Net; the novel view's extra terms really back-propagate (the step differs from one
+    without them)."""
+    from mi3d import rays as R, refine, sd_standin as S
+    torch.manual_seed(0)
+    P, H = 4000, 64
+    d = torch.randn(P, 3, device=cuda)
+    points = (d / d.norm(dim=-1, keepdim=True) * 0.35).contiguous()
+    g = S.StableDiffusionStandIn(cuda, dtype=torch.float32, unet_kw=dict(ch=(64, 64, 64, 64), ctx_dim=32, layers=1),
+                                 vae_kw=dict(ch=(32, 32, 32, 32), layers=1))
+    text_z = torch.randn(2, 77, 32, device=cuda)
+    w2c = torch.linalg.inv(R.orbit_pose(1.25, 80.0, 30.0, device=cuda)[0])
+    focal = 1.0 / (2 * np.tan(np.radians(20) / 2))
+    clip = S.CLIPStandIn(width=64, layers=2, heads=2, embed=32, text_width=32, text_layers=2, text_heads=2).to(cuda)
+    cx = refine.ContextualLoss().to(cuda)
+    for p in list(clip.parameters()) + list(cx.parameters()):
+        p.requires_grad_(False)
+    ref_rgb = torch.rand(1, 3, H, H, device=cuda)
+    gt_mask = (torch.rand(1, 1, H, H, device=cuda) > 0.3).float()
+
+    def fresh():
+        torch.manual_seed(1)
+        colour = torch.nn.Parameter(torch.rand(P, 3, device=cuda))
+        feat = torch.nn.Parameter(torch.randn(P, 16, device=cuda))
+        unet = refine.UNet(num_input_channels=19).to(cuda).train()
+        opt = torch.optim.Adam([colour, feat] + list(unet.parameters()), lr=1e-3)
+        return colour, feat, unet, (unet, {"colour": colour, "feat": feat}, opt, g, text_z, points, w2c, focal, H, H,
+                                   2.0 / H * 2.0, 8, colour.detach().clone())
+    # front view
+    colour, feat, unet, args = fresh()
+    c0, f0, w0 = colour.detach().clone(), feat.detach().clone(), unet.start.block["conv_f"].weight.detach().clone()
+    loss = refine.refine_train_step(*args, is_front=True, ref_rgb=ref_rgb, gt_mask=gt_mask)
+    assert torch.isfinite(loss) and float(loss) > 0
+    assert float((colour - c0).abs().max()) > 0 and float((feat - f0).abs().max()) > 0
+    assert float((unet.start.block["conv_f"].weight - w0).abs().max()) > 0
+    with pytest.raises(ValueError):
+        refine.refine_train_step(*args, is_front=True)
+    # novel view, with and without the trainer-level terms (same seeds, same timestep: the SDS branch)
+    outs = []
+    for extra in (False, True):
+        colour, feat, unet, args = fresh()
+        torch.manual_seed(7)
+        kw = dict(clip_model=clip, ref_rgb=ref_rgb, ref_text="a toy", cx_model=cx) if extra else {}
+        loss = refine.refine_train_step(*args, t=500, **kw)
+        assert torch.isfinite(loss)
+        outs.append((float(loss), feat.detach().clone()))
+    assert outs[1][0] != outs[0][0] and float((outs[1][1] - outs[0][1]).abs().max()) > 0

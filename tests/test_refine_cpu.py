@@ -44,3 +44,50 @@ def test_raster_oracle_on_hand_checkable_cases():
     assert np.allclose(img[:, 2, 5], [a0, (1 - a0) * a1], atol=1e-6)
     g = R.alpha_composite_backward(idx, w, np.ones((2, H, W), np.float32), 3)
     assert np.allclose(g[0], [a0, a0], atol=1e-6) and np.allclose(g[1], 0) and np.allclose(g[2], (1 - a0) * a1, atol=1e-6)
+
+
+def test_contextual_loss_properties():
+    """mi3d.refine.contextual_loss (the `contextual_loss` package's cosine form restated; nerf/utils.py:810,881): zero for
+    identical feature maps, positive otherwise, unchanged when the positions of either map are permuted (it matches
+    positions by feature similarity, not by place), and differentiable w.r.t. its first argument."""
+    from mi3d import refine
+    torch.manual_seed(0)
+    y = torch.randn(1, 16, 6, 6)
+    assert float(refine.contextual_loss(y.clone(), y)) < 1e-3
+    x = torch.randn(1, 16, 6, 6, requires_grad=True)
+    l = refine.contextual_loss(x, y)
+    assert float(l) > 0.5
+    perm = torch.randperm(36)
+    xp = x.reshape(1, 16, 36)[:, :, perm].reshape(1, 16, 6, 6)
+    yp = y.reshape(1, 16, 36)[:, :, torch.randperm(36)].reshape(1, 16, 6, 6)
+    assert abs(float(refine.contextual_loss(xp, y)) - float(l)) < 1e-5
+    assert abs(float(refine.contextual_loss(x, yp)) - float(l)) < 1e-5
+    l.backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    # moving x towards y lowers the loss
+    with torch.no_grad():
+        closer = 0.2 * x + 0.8 * y
+    assert float(refine.contextual_loss(closer, y)) < float(l)
+
+
+def test_vgg19_feature_stack_and_trainer_level_clip_term():
+    """VGG19 `features` to relu5_4 (16 convolutions, 4 pools: 1/16 resolution, 512 channels, 20.0 M parameters) and the
+    trainer's CLIP image-image term (nerf/utils.py:434-441) - which, unlike the guidance's denoise branch, back-propagates
+    into the render."""
+    from mi3d import refine, sd_standin as S
+    vgg = refine.VGG19Features()
+    assert sum(p.numel() for p in vgg.parameters()) == 20_024_384          # torchvision vgg19.features[:36]
+    assert sum(isinstance(m, torch.nn.Conv2d) for m in vgg.features) == 16
+    with torch.no_grad():
+        f = vgg(torch.rand(1, 3, 64, 64))
+    assert f.shape == (1, 512, 4, 4) and float(f.min()) >= 0
+    cx = refine.ContextualLoss()
+    clip = S.CLIPStandIn(width=32, layers=1, heads=2, embed=16, text_width=16, text_layers=1, text_heads=2)
+    for p in clip.parameters():
+        p.requires_grad_(False)
+    rgb = torch.rand(1, 3, 48, 48, requires_grad=True)
+    ref = torch.rand(1, 3, 64, 64)
+    loss = 10 * refine.img_clip_loss(clip, rgb, ref) + cx(rgb, ref)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(rgb.grad).all() and float(rgb.grad.abs().max()) > 0
+    assert -10.0 - 1e-4 <= float(10 * refine.img_clip_loss(clip, ref, ref)) <= -10.0 + 1e-3   # identical images: cosine 1

@@ -207,6 +207,22 @@ def main():
         out = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240)
         res["scatter_fp32_P13_checksum"] = int(out.view(torch.int32).to(torch.int64).sum())   # (A/B across builds)
         del g, out
+    if "scatter_ab" in what:  # the 13-point scatter (+ the deferred point-0 pair) under dev settings, dense and real census
+        out = {}
+        ex = torch.randn(16, n, 2, device=dev).to(feats.dtype)
+        for census in (False, True):
+            a.real_census = census
+            g = gradient_planes(feats.dtype)
+            for name, kvs in (("base", {}), ("no_face_pass", {10: 0x10000}), ("merge42", {15: 42}), ("merge58", {15: 58}),
+                              ("merge42_no_face", {15: 42, 10: 0x10000}), ("base_again", {})):
+                for k, v in kvs.items():
+                    tune(k, v)
+                out[("real_" if census else "dense_") + name] = timeit(lambda: field_ops.scatter_binned(
+                    xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex), a.iters)
+                for k in kvs:
+                    tune(k, -1)
+            del g
+        res["scatter13_plus_ms"] = out
     if "scatter_diag" in what:  # the coarse role alone, with its gather-table atomics switched off (timing only)
         g = gradient_planes(feats.dtype)
         out = {}
