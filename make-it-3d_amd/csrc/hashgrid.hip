@@ -775,12 +775,15 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
 }
 
 // The record path sums a tile in the gather table only where it pays: on levels whose cells are at least this many
-// marching steps long (divided by default_merge_levels' own 1.05); the others emit per-point x-pair records.  3 steps =
-// levels 0-7 at C2.  The gathered role is bound by its instruction stream, the record role by bytes, and in a real step
-// (half the binary16 gradient pairs are zeros: fewer records, same instructions) the gathered role is the one the launch
-// waits for, so a threshold of 4.2 steps (level 7 -> records) was measured: a whole field iteration 89.5 -> 86.4 ms
-// (5.8: 87.5, 8.0: 92.4), but the dense-gradient scatter 58 -> 66 ms and 8 GiB more arena - not adopted.
-inline float merge_steps() { return (float)MI3D_TUNE(MI3D_T_MERGE_STEPS_X10, 30) / 10.5f; }
+// marching steps long (divided by default_merge_levels' own 1.05); the others emit per-point x-pair records.  4 steps =
+// levels 0-6 at C2.  The gathered role is bound by its instruction stream and its LDS atomics whatever the gradients
+// are, the record role by records, i.e. by how many gradient pairs are not zero.  Round 3 measured the threshold at 16-byte
+// records (3 steps: level 7 gathered) - a real field iteration preferred 4.2 (89.5 -> 86.4 ms) but the dense-gradient
+// scatter paid 58 -> 66 ms.  With 12-byte binary16 records and the shared-face pass (round 4) level 7 as records wins
+// on both: 13-point scatter + deferred point-0 pair, one box, tools/kbench.py --what scatter_ab: dense gradients 62.25 ->
+// 61.57 ms, a real step's zero census 40.87 -> 39.77 ms, whole steps -1.9 ms (tools/step_ab.py, anchored A/B); 5.8 steps
+// (level 6 as records too): real 39.1, dense 66.2 - not taken (profiles/kbench_r04_scatter_ab.json).
+inline float merge_steps() { return (float)MI3D_TUNE(MI3D_T_MERGE_STEPS_X10, 42) / 10.5f; }
 
 // levels whose cells are longer than one marching step `step01` (in [0,1] units) try to merge neighbours
 uint32_t default_merge_levels(const GridTable &T, float step01) {

@@ -39,7 +39,7 @@ enum : int {
     MI3D_T_MARCH_RPW_MIN = 13,     // march: smallest rays per wave the launch may choose
     MI3D_T_MARCH_WAVES = 14,       // march: persistent waves
     MI3D_T_MERGE_STEPS_X10 = 15,   // scatter: a level is gathered per tile (coarse role) if its cells are >= this / 10.5
-                                   //          marching steps long (product: 30 -> levels 0-7 at C2)
+                                   //          marching steps long (product: 42 -> levels 0-6 at C2)
     MI3D_T_ENCODE_LDS_LEVELS = 16, // gather: levels served from LDS (default: as many as fit)
     MI3D_T_ENCODE_STATIC_TILES = 17,  // gather: 1 = tiles dealt statically (round 2's order) instead of claimed
 };
