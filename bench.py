@@ -636,14 +636,16 @@ def main():
                  "algorithmic bytes = 1024 B per field evaluation; the tables are L2-resident per XCD, so the binding "
                  "limit is the L1 line-lookup rate for divergent gathers, not HBM - traffic shows how few bytes reach it",
                  "k_grid_encode_planes"),
-            roof("grid gradient scatter: one mi3d_grid_scatter_binned call = (k_bin_emit + k_bin_reduce) x slices "
+            roof("grid gradient scatter: one mi3d_grid_scatter_binned_plus call = (k_bin_emit + k_bin_reduce) x slices "
                  "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
                  "GB/s", "a 'launch' here is one scatter call (kernel-trace: sum the k_bin_emit and k_bin_reduce rows of a "
-                 "step); algorithmic bytes = 2048 B per evaluation read-modify-write of the table, counted ONLY for the "
-                 "(evaluation, level) gradient pairs that are not exactly zero (grad_nonzero_pair_fraction: binary16 "
-                 "gradients underflow, and adding a zero is what the reference's atomics would do); the dense-gradient "
-                 "figure is scatter_dense_gradients.  One call per NeRF backward: the SDS pass reaches stencil point 0 "
-                 "only (1/13 of the evaluations), the regulariser pass all 13",
+                 "step: profiles/kernel_stats_r04_bench_steps.csv, collected on THIS command's own timed steps with "
+                 "--profile-run); algorithmic bytes = 2048 B per evaluation read-modify-write of the table, counted ONLY for "
+                 "the (evaluation, level) gradient pairs that are not exactly zero (grad_nonzero_pair_fraction: binary16 "
+                 "gradients underflow, and adding a zero is what the reference's atomics would do); dense-gradient figures: "
+                 "scatter_dense_gradients (the call alone) and dense_gradient_step (a whole step).  ONE call per step: the "
+                 "SDS pass (nerf/sd.py:171) reaches stencil point 0 only, its gradient planes are parked and ride along in "
+                 "the regulariser pass's 13-point scatter (mi3d.grid_ops.DEFER_POINT0)",
                  "scatter_binned", work_of=scatter_work),
             roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
                  "streams 64 B of binary16 planes in + 16 B out per evaluation (fp32 planes without autocast: 128 B)", "k_mlp_forward"),

@@ -32,7 +32,7 @@ extern "C" {
 #define MI3D_MAX_LEVELS 16
 #define MI3D_MAX_POINTS 16
 
-/* library / device sanity: returns the ABI version; *n_devices_host gets hipGetDeviceCount (or -1) */
+/* the ABI version: 3 (2 + mi3d_grid_scatter_binned_plus; every version-2 entry point is unchanged) */
 int mi3d_abi_version(void);
 const char *mi3d_last_error_string(int err);
 

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 2; }
+int mi3d_abi_version(void) { return 3; }
 const char *mi3d_last_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
 int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
