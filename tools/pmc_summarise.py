@@ -1,5 +1,10 @@
 """rocprofv3 --pmc counter_collection CSVs -> profiles/pmc_rNN.json.
-    python tools/pmc_summarise.py <out json> <workload> <evals per full launch> <csv> [<csv> ...]
+    python tools/pmc_summarise.py <out json> <workload> <evals per full launch> [--tail K/T] <csv> [<csv> ...]
+--tail K/T: the passes wrap `bench.py --profile-run`, T = its steps_run_total identical steps of which the LAST K are the
+timed ones; only the last K/T of every family's dispatches (in dispatch order) are averaged - the untimed steps in front of
+them settle the loss scale from 65536, where the binary16 gradients are full of inf / NaN and the scatter's emit hands
+those to float atomics (its WRITE_SIZE is 10 x the settled steps' there).  A family whose dispatch count is not a multiple
+of T (kernels the grid refresh adds every 16th step) keeps all its dispatches.
 Every CSV is one --pmc pass of tools/field_bench.py (FETCH_SIZE and WRITE_SIZE need a pass each: TCC slots).  For each
 kernel family the per-launch averages of every counter are recorded, plus
   hbm_bytes_per_eval = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / evals   (gfx950: FETCH_SIZE counts wide reads at half
@@ -31,10 +36,20 @@ def family(kernel_name):
     return None
 
 
+# WRITE_SIZE counts 32-byte sectors touched, not bytes (tools/write_calib.hip, profiles/write_calib_r04.txt): exact for
+# coalesced streams of 4 / 12 / 16 bytes per lane, x 1.29 for 12-byte records in runs of 8 at 4-byte-aligned places (the
+# emit's sorted runs), x 1.125 for 16-byte records in such runs, x 3.3 for lone 12-byte records.
+WRITE_CALIBRATION = {"k_bin_emit": 1.29}
+
+
 def main():
-    out, workload, evals = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    args = sys.argv[1:]
+    tail = None
+    if "--tail" in args:
+        i = args.index("--tail"); k, t = args[i + 1].split("/"); tail = (int(k), int(t)); del args[i:i + 2]
+    out, workload, evals = args[0], args[1], float(args[2])
     acc = {}
-    for path in sys.argv[4:]:
+    for path in args[3:]:
         for r in csv.DictReader(open(path)):
             fam = family(r["Kernel_Name"])
             if fam is None:
@@ -48,7 +63,9 @@ def main():
         for (f, counter), vals in acc.items():
             if f != fam:
                 continue
-            v = [x for _, x in vals]
+            v = [x for _, x in sorted(vals)]
+            if tail is not None and len(v) % tail[1] == 0:
+                v = v[len(v) - len(v) // tail[1] * tail[0]:]
             big = max(v)
             full = [x for x in v if x >= 0.5 * big] or v
             small = [x for x in v if x < 0.5 * big]
@@ -58,7 +75,9 @@ def main():
         g = lambda c: rec.get(c, {}).get("per_launch_full")
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
             rec["fetch_bytes_per_launch_corrected_x2"] = 2.0 * g("FETCH_SIZE") * 1024.0
-            rec["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+            rec["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0 / WRITE_CALIBRATION.get(fam, 1.0)
+            if fam in WRITE_CALIBRATION:
+                rec["write_size_calibration_divisor"] = WRITE_CALIBRATION[fam]
             rec["evals_per_launch"] = evals
             rec["hbm_bytes_per_eval"] = (rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]) / evals
         if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("GRBM_GUI_ACTIVE"):
@@ -71,8 +90,8 @@ def main():
     parts = [db[f][workload] for f in ("k_bin_emit", "k_bin_emit16", "k_bin_reduce") if f in db and workload in db[f]]
     calls = db.get("k_mlp_backward", {}).get(workload, {}).get("FETCH_SIZE", {}).get("launches_full", 0)
     if parts and calls and all("FETCH_SIZE" in p and "WRITE_SIZE" in p for p in parts):
-        total = sum((2.0 * p["FETCH_SIZE"]["per_launch_full"] * p["FETCH_SIZE"]["launches_full"] +
-                     p["WRITE_SIZE"]["per_launch_full"] * p["WRITE_SIZE"]["launches_full"]) * 1024.0 for p in parts)
+        total = sum((p["fetch_bytes_per_launch_corrected_x2"] * p["FETCH_SIZE"]["launches_full"] +
+                     p["write_bytes_per_launch"] * p["WRITE_SIZE"]["launches_full"]) for p in parts)
         db.setdefault("scatter_binned", {})[workload] = {
             "hbm_bytes_per_eval": total / calls / evals, "calls": calls,
             "note": "emit (+ emit16) + reduce launches of one full-size scatter call (all slices), FETCH x2 + WRITE"}
