@@ -34,8 +34,13 @@ import torch.nn.functional as F
 # Measured (tools/sd_knobs.py, profiles/sd_knobs_r04.json; one box, 10 calls each): GN_SPLIT_STATS 34.1 -> 32.2 ms per
 # guidance call (VAE encode 11.4 -> 9.5, backward unchanged) - ON; VAE_HALF_CACHE 34.07 -> 34.25 / 32.22 -> 32.13, i.e.
 # nothing (the casts are 60 small kernels on otherwise idle CUs) - OFF, the encoder keeps the reference's fp32 weights.
+#   VAE_GRAPH       the VAE encoder's forward AND backward (it is differentiated down to the rendered image every step,
+#                   nerf/sd.py:171) as two captured hipGraphs inside one autograd node (torch.cuda.make_graphed_callables):
+#                   ~300 + ~600 launches per step replayed instead of issued.  Fixed shape ([1, 3, 512, 512], what
+#                   sd.py:124 always feeds it), frozen weights, autocast(float16) only; anything else runs eagerly.
 GN_SPLIT_STATS = True
 VAE_HALF_CACHE = False
+VAE_GRAPH = False
 
 
 class _SplitStatsGroupNorm(torch.autograd.Function):
@@ -383,8 +388,37 @@ class StableDiffusionStandIn(nn.Module):
             self.__dict__["_vae_encoder_half"] = half      # (not a registered sub-module: state_dict stays the fp32 model's)
         return half
 
+    def _vae_moments(self, x):
+        """vae_encoder(x): through the graphed callable (VAE_GRAPH) when x is the [1, 3, 512, 512] image under
+        autocast(float16) on the GPU, eagerly otherwise."""
+        enc = self._vae_encoder_for(x)
+        if not (VAE_GRAPH and x.is_cuda and tuple(x.shape) == (1, 3, 512, 512) and x.dtype == torch.float32
+                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+                and not torch.cuda.is_current_stream_capturing()):
+            return enc(x)
+        key = (id(enc), GN_SPLIT_STATS, x.requires_grad)
+        cached = self.__dict__.get("_vae_graphed")
+        if cached is None or cached[0] != key:
+            if self.__dict__.get("_vae_graph_failed"):
+                return enc(x)
+            try:
+                sample = torch.rand(1, 3, 512, 512, device=x.device, requires_grad=x.requires_grad)
+                with torch.autocast("cuda", dtype=torch.float16, cache_enabled=False):   # (capture needs the cast cache off)
+                    graphed = torch.cuda.make_graphed_callables(enc, (sample,), allow_unused_input=True)
+                cached = (key, graphed)
+                self.__dict__["_vae_graphed"] = cached
+            except RuntimeError as e:
+                if isinstance(e, torch.cuda.OutOfMemoryError):
+                    raise
+                import warnings
+                warnings.warn(f"VAE encoder hipGraph capture unavailable, running eagerly: {str(e).splitlines()[0]}")
+                self.__dict__["_vae_graph_failed"] = True
+                torch.cuda.synchronize(x.device)
+                return enc(x)
+        return cached[1](x)
+
     def encode_imgs(self, imgs):
-        moments = self._vae_encoder_for(imgs)(2 * imgs - 1)
+        moments = self._vae_moments(2 * imgs - 1)
         mean, logvar = moments.chunk(2, 1)
         std = torch.exp(0.5 * logvar.clamp(-30, 20))
         return (mean + std * torch.randn_like(mean)) * 0.18215
