@@ -418,3 +418,60 @@ def test_adan_kernel_against_the_reference_optimizer_on_the_gpu(ref, cuda):
     for p, q in zip(a_p, b_p):
         for k in ("exp_avg", "exp_avg_sq", "exp_avg_diff"):
             assert torch.allclose(a.state[p][k], b.state[q][k], rtol=5e-5, atol=1e-9), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4's shape and the eval loop at BASELINE config 2's size, on the reference route
+
+def test_c4_view_forward_render_matches_the_reference_route(ref, cuda):
+    """One view of BASELINE config 4 - 256 x 256 rays, max_steps 2048, pruned occupancy (sphere 0.5: ~36 M samples x 7
+    field evaluations), training-mode forward render, fp32 - through the reference's run_cuda on the drop-in packages and
+    through the product: image / depth / weights 1e-4, the orientation loss 2e-4."""
+    from mi3d import rays as R, sds_step
+    theirs, ours, opt = _pair(ref, cuda, lambda_smooth=0.0, max_steps=2048)
+    for m in (theirs, ours):
+        sds_step.set_bitfield(m, 0.5)
+    ro, rd, ds = R.view_rays(256, 256, device=cuda)
+    outs = []
+    for model in (theirs, ours):
+        model.train()
+        torch.manual_seed(13)
+        with torch.no_grad():
+            outs.append(model.render(ro, rd, depth_scale=ds, bg_color=torch.full((3,), 0.7, device=cuda), perturb=True,
+                                     ambient_ratio=1.0, shading="albedo", force_all_rays=True, dt_gamma=0, max_steps=2048))
+        torch.cuda.empty_cache()
+    n = int(ours.step_counter[0, 0])
+    assert n == int(theirs.step_counter[0, 0]) and 25_000_000 < n < 45_000_000
+    _outputs_close(outs[0], outs[1], rtol=1e-4, atol=1e-6)
+    lo = [float(o["loss_orient"]) for o in outs]
+    assert abs(lo[1] - lo[0]) <= 2e-4 * abs(lo[0])
+    REPORT["c4_view_forward_fp32"] = {"samples": n, "loss_orient": lo,
+                                      "image_max_abs_diff": float((outs[0]["image"] - outs[1]["image"]).abs().max())}
+
+
+def test_eval_loop_at_c2_size_matches_the_reference_route(ref, cuda):
+    """The inference branch (renderer.py:526-551) at BASELINE config 2's ray count and step budget on a refreshed
+    occupancy grid: the reference's host loop on the drop-in march_rays / composite_rays against the product's
+    graph-replayed, device-driven loop - image, depth, weights 1e-4, normal map 2e-3 absolute."""
+    from mi3d import rays as R
+    theirs, ours, opt = _pair(ref, cuda, lambda_smooth=0.0, max_steps=1024)
+    torch.manual_seed(3)
+    ours.update_extra_state()
+    theirs.density_grid.copy_(ours.density_grid)
+    theirs.density_bitfield.copy_(ours.density_bitfield)
+    theirs.mean_density = ours.mean_density
+    ro, rd, ds = R.view_rays(128, 128, device=cuda)
+    outs = []
+    for m in (theirs, ours):
+        m.eval()
+        with torch.no_grad():
+            torch.manual_seed(11)
+            outs.append(m.render(ro, rd, depth_scale=ds, bg_color=torch.ones(3, device=cuda), perturb=False,
+                                 ambient_ratio=1.0, shading="albedo", dt_gamma=0, max_steps=1024))
+    a, b = outs
+    assert float(a["weights_sum"].max()) > 0.5 and ours.infer_stats["graph_replays"] >= 1
+    _outputs_close(a, b, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["normal"].cpu().numpy(), a["normal"].cpu().numpy(), rtol=0, atol=2e-3)
+    REPORT["eval_loop_c2_size"] = {"rounds_launched": ours.infer_stats["rounds_launched"],
+                                   "host_reads": ours.infer_stats["host_reads"],
+                                   "image_max_abs_diff": float((a["image"] - b["image"]).abs().max())}

@@ -213,8 +213,9 @@ def main():
         for census in (False, True):
             a.real_census = census
             g = gradient_planes(feats.dtype)
-            for name, kvs in (("base", {}), ("no_face_pass", {10: 0x10000}), ("merge42", {15: 42}), ("merge58", {15: 58}),
-                              ("merge42_no_face", {15: 42, 10: 0x10000}), ("base_again", {})):
+            for name, kvs in (("base", {}), ("no_face_pass", {10: 0x10000}), ("merge30", {15: 30}), ("merge58", {15: 58}),
+                              ("fine_waves1024", {3: 1024}), ("fine_waves1280", {3: 1280}), ("fine_waves2048", {3: 2048}),
+                              ("coarse_waves8192", {4: 8192}), ("base_again", {})):
                 for k, v in kvs.items():
                     tune(k, v)
                 out[("real_" if census else "dense_") + name] = timeit(lambda: field_ops.scatter_binned(
