@@ -224,7 +224,9 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
  *   out[0] samples per slice, out[1] workspace bytes one slice uses, out[2] coarse levels (gathered per tile),
  *   out[3] reduce workgroups, out[4] record-arena bytes, out[5] region counters, then 7 values per level: bins, region
  *   capacity (records), emitting waves, 1 = 16-byte x-pair records, reduce workgroups per bin, first reduce workgroup,
- *   first region counter.  out must hold 6 + 7 * n_levels values.
+ *   first region counter.  out must hold 6 + 7 * n_levels values.  (The layout for fp32 gradient planes, 16-byte pair
+ *   records - what mi3d_grid_scatter_binned_workspace sizes; with binary16 planes the pair records take 12 bytes, so the
+ *   same workspace holds more samples per slice than this query says.)
  * mi3d_grid_level_routes: which index route the plane gather and the scatter's emit take on each level (kinds[n_levels]):
  *   0 the general rule (any dims, any table size, any input - tcnn's grid_index as the oracle restates it), 1 dense 3-D
  *   strided (24-bit multiplies, at most one wrap), 2 power-of-two hash (mask).  `stencil_points` != 0: the positions are

@@ -185,6 +185,8 @@ def _park(param, key, item):
     older = [it for it in pend if it["key"] == key]
     if older:                       # a second point-0 pass through the same forward: complete the first one now
         flush_pending(param, key)
+    if len(pend) >= 2:              # planes of forwards nobody came back to: complete them rather than pile them up
+        flush_pending(param)
     item["key"] = key
     item["event"] = torch.cuda.current_stream(item["x"].device).record_event()
     pend.append(item)

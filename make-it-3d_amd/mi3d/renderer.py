@@ -10,6 +10,7 @@ What differs is how the work is issued, not what is computed:
 `export_mesh` (marching cubes + xatlas + nvdiffrast, renderer.py:142-330) is outside the hot path and not provided.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -57,6 +58,10 @@ def near_far_from_bound(rays_o, rays_d, bound, type="cube", min_near=0.05):
         near[miss] = 1e9
         far[miss] = 1e9
         return torch.clamp(near, min=min_near), far
+
+
+# per-model buffers and captured graphs of the inference loop (NeRFRenderer._infer_state): keyed weakly by the module
+_INFER_CACHES = weakref.WeakKeyDictionary()
 
 
 class NeRFRenderer(nn.Module):
@@ -265,7 +270,7 @@ class NeRFRenderer(nn.Module):
     def _infer_state(self, N, device, perturb):
         """Caller-owned buffers of the loop for N rays, kept across renders: a captured graph of rounds holds their
         addresses."""
-        cache = self.__dict__.setdefault("_infer_cache", {})
+        cache = _INFER_CACHES.setdefault(self, {})   # (not an attribute: copy.deepcopy(model) must not meet a CUDAGraph)
         st = cache.get((N, str(device)))
         if st is None:
             align = 128
