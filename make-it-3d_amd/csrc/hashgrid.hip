@@ -855,22 +855,11 @@ constexpr uint32_t kRowEntryBits = 19;
 // The reduce forms (1 - fx) w (a, b) and fx w (a, b) from them.  fx_q == 0 marks a single, as fx == 0 does above.
 // A quarter less of the arena, of the emit's stores and of the reduce's loads - which is what bounds the reduce (it
 // reads its records at the HBM rate: 72 GB per dense 13-point pass with 16-byte records, profiles/pmc_r03.json).
-struct Row12 { uint32_t w0, w1, w2; };
-constexpr float kFix23 = 8388608.0f, kUnfix23 = 1.0f / 8388608.0f;
-__device__ __forceinline__ uint32_t fix23(float v) {   // v in [0, 1]
-    const uint32_t q = (uint32_t)(v * kFix23 + 0.5f);
-    return q < 8388607u ? q : 8388607u;
-}
-__device__ __forceinline__ Row12 pack_row12(uint32_t e_local, uint32_t t, float w, float fx, uint32_t raw_pair) {
-    const uint32_t wq = fix23(w), fq = fix23(fx);
-    return Row12{e_local | (t << 13) | ((wq >> 16) << 18) | ((fq >> 16) << 25), raw_pair, (wq & 0xFFFFu) | ((fq & 0xFFFFu) << 16)};
-}
+// (Row12, pack_row12 / unpack_row12 and the x-pair rule pair_flip_t live in mi3d_common.h: tests/test_host_math.py
+// compiles them for the host)
 __device__ __forceinline__ void unpack_row12(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t &e_local, uint32_t &t, float &w,
                                              float &fx, float &dx, float &dy) {
-    e_local = w0 & 8191u;
-    t = (w0 >> 13) & 31u;
-    w = (float)((((w0 >> 18) & 127u) << 16) | (w2 & 0xFFFFu)) * kUnfix23;
-    fx = (float)(((w0 >> 25) << 16) | (w2 >> 16)) * kUnfix23;
+    unpack_row12_fields(w0, w2, e_local, t, w, fx);
     dx = (float)__builtin_bit_cast(_Float16, (unsigned short)(w1 & 0xFFFFu));
     dy = (float)__builtin_bit_cast(_Float16, (unsigned short)(w1 >> 16));
 }

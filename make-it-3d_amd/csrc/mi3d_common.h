@@ -190,4 +190,33 @@ MI3D_HD void grid_cell(float x, float scale, uint32_t &cell, float &w) {
     w = p - fl;
 }
 
+// ---- the scatter's 12-byte x-pair record (binary16 gradient planes; hashgrid.hip k_bin_emit / k_bin_reduce) ---------------
+// The two x-neighbours of a (y, z) corner pair differ in their entry's low bits only, because x enters the hash with prime 1:
+// e(x + 1) = e(x) ^ (2^t - 1) (masked to the level), t = 1 + trailing ones of cx (a +1 carry flips exactly those bits); a
+// dense level's pair is e, e + 1 (t = 0).  One record carries both contributions - (1 - fx) w (a, b) and fx w (a, b), w = w_y w_z:
+//   word 0 = entry & 8191 | t << 13 | (w_q >> 16) << 18 | (fx_q >> 16) << 25      word 1 = the raw binary16 pair (a, b)
+//   word 2 = (w_q & 0xFFFF) | (fx_q & 0xFFFF) << 16          w_q = round(w 2^23), fx_q = round(fx 2^23), clamped below 2^23
+// |w - w_q 2^-23| <= 2^-24 (2^-23 at w = 1, the clamp): the last bit of an fp32 weight near 1.
+struct Row12 { uint32_t w0, w1, w2; };
+constexpr float kFix23 = 8388608.0f, kUnfix23 = 1.0f / 8388608.0f;
+MI3D_HD uint32_t fix23(float v) {   // v in [0, 1]
+    const uint32_t q = (uint32_t)(v * kFix23 + 0.5f);
+    return q < 8388607u ? q : 8388607u;
+}
+MI3D_HD uint32_t pair_flip_t(uint32_t cx) {   // hashed levels: how many low bits of the entry a +1 in x flips
+    uint32_t t = 1;
+    while (cx & 1u) { cx >>= 1; ++t; }
+    return t;
+}
+MI3D_HD Row12 pack_row12(uint32_t e_local, uint32_t t, float w, float fx, uint32_t raw_pair) {
+    const uint32_t wq = fix23(w), fq = fix23(fx);
+    return Row12{e_local | (t << 13) | ((wq >> 16) << 18) | ((fq >> 16) << 25), raw_pair, (wq & 0xFFFFu) | ((fq & 0xFFFFu) << 16)};
+}
+MI3D_HD void unpack_row12_fields(uint32_t w0, uint32_t w2, uint32_t &e_local, uint32_t &t, float &w, float &fx) {
+    e_local = w0 & 8191u;
+    t = (w0 >> 13) & 31u;
+    w = (float)((((w0 >> 18) & 127u) << 16) | (w2 & 0xFFFFu)) * kUnfix23;
+    fx = (float)(((w0 >> 25) << 16) | (w2 >> 16)) * kUnfix23;
+}
+
 }  // namespace mi3d

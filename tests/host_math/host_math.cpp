@@ -59,4 +59,24 @@ void hm_grid_corners(const float* x, uint32_t n, float scale, uint32_t res, uint
         }
     }
 }
+
+// the scatter's 12-byte pair record: pack, unpack, and the x-pair rule on a hashed level of `size` (a power of two) entries
+void hm_row12_roundtrip(const uint32_t* e_local, const uint32_t* t, const float* w, const float* fx, const uint32_t* raw,
+                        uint32_t n, uint32_t* words, uint32_t* e_out, uint32_t* t_out, float* w_out, float* fx_out) {
+    for (uint32_t i = 0; i < n; i++) {
+        const Row12 r = pack_row12(e_local[i], t[i], w[i], fx[i], raw[i]);
+        words[i*3] = r.w0; words[i*3+1] = r.w1; words[i*3+2] = r.w2;
+        unpack_row12_fields(r.w0, r.w2, e_out[i], t_out[i], w_out[i], fx_out[i]);
+    }
+}
+void hm_pair_rule(const uint32_t* cell, uint32_t n, uint32_t size, uint32_t* e0, uint32_t* e1, uint32_t* e1_from_rule) {
+    GridLevel L{1.0f, 0u, 0u, size, 1u, 3u};
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t cx = cell[i*3], cy = cell[i*3+1], cz = cell[i*3+2];
+        e0[i] = grid_entry(L, cx, cy, cz);
+        e1[i] = grid_entry(L, cx + 1, cy, cz);
+        const uint32_t t = pair_flip_t(cx);
+        e1_from_rule[i] = e0[i] ^ (((t >= 32 ? 0xFFFFFFFFu : (1u << t) - 1u)) & (size - 1u));
+    }
+}
 }

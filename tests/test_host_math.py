@@ -94,3 +94,38 @@ def test_grid_corner_indices_bit_exact_with_oracle(hm, oracle, kw):
         ref_local = idx_ref[:, l, :] - (0 if idx_ref[:, l, :].max() < size else offs[l])
         assert np.array_equal(idx, ref_local.astype(np.uint32)), l
         assert np.array_equal(w.view(np.uint32), w_ref[:, l, :].view(np.uint32)), l
+
+
+def test_row12_record_packing_and_the_x_pair_rule(hm):
+    """The scatter's 12-byte pair record under autocast (csrc/mi3d_common.h: pack_row12 / unpack_row12_fields, used by
+    k_bin_emit / k_bin_reduce): the entry's 13 bits, the flip count and the raw binary16 pair survive exactly, the weight and
+    the x fraction come back within 2^-24 (2^-23 at exactly 1, the clamp) - and the rule the record relies on: on a hashed
+    power-of-two level the entry of the x + 1 corner is the x corner's with its t low bits flipped, t = 1 + trailing ones of
+    cx (x enters the hash with prime 1)."""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    e = rng.integers(0, 8192, n).astype(np.uint32)
+    t = rng.integers(0, 14, n).astype(np.uint32)
+    w = rng.uniform(0, 1, n).astype(np.float32)
+    fx = rng.uniform(0, 1, n).astype(np.float32)
+    w[:6] = [0.0, 1.0, 2.0 ** -24, 1 - 2.0 ** -24, 0.5, 2.0 ** -23]
+    fx[:6] = [0.0, 2.0 ** -25, 1 - 2.0 ** -24, 0.25, 2.0 ** -23, 0.75]
+    raw = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    words = np.empty((n, 3), np.uint32)
+    e2, t2 = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    w2, fx2 = np.empty(n, np.float32), np.empty(n, np.float32)
+    hm.hm_row12_roundtrip(_p(e), _p(t), _p(w), _p(fx), _p(raw), C.c_uint32(n), _p(words), _p(e2), _p(t2), _p(w2), _p(fx2))
+    assert np.array_equal(e2, e) and np.array_equal(t2, t) and np.array_equal(words[:, 1], raw)
+    assert np.abs(w2.astype(np.float64) - w).max() <= 2.0 ** -23 and np.abs(w2.astype(np.float64) - w)[w < 1].max() <= 2.0 ** -24 + 1e-12
+    assert np.abs(fx2.astype(np.float64) - fx).max() <= 2.0 ** -24 + 1e-12
+    assert w2[0] == 0.0 and fx2[0] == 0.0 and fx2[1] == 0.0          # fx_q == 0 marks a single: 2^-25 rounds to it
+    assert (w2 < 1.0).all() and (fx2 < 1.0).all()
+    # the x-pair rule, for cells of every trailing-ones pattern, on the levels the reference hashes into 2^19 (and a 2^12)
+    cells = rng.integers(0, 2048, (100_000, 3)).astype(np.uint32)
+    cells[:4096, 0] = np.arange(4096)            # every low-bit pattern of cx
+    for size in (1 << 19, 1 << 12):
+        e0, e1, rule = (np.empty(100_000, np.uint32) for _ in range(3))
+        hm.hm_pair_rule(_p(cells), C.c_uint32(100_000), C.c_uint32(size), _p(e0), _p(e1), _p(rule))
+        assert np.array_equal(e1, rule), size
+        same_bin = (e0 >> 13) == (e1 >> 13)      # what the emit sends as ONE record (the others leave as two singles)
+        assert 0.99 < same_bin.mean() <= 1.0
