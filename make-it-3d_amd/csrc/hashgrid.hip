@@ -1734,7 +1734,10 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     }
 
     bool any = false;
-    constexpr uint32_t U = 8;  // records in flight per lane
+#ifndef MI3D_REDUCE_U
+#define MI3D_REDUCE_U 8
+#endif
+    constexpr uint32_t U = MI3D_REDUCE_U;  // records in flight per lane
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
         uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
         cnt = cnt < cap ? cnt : cap;

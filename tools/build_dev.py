@@ -19,7 +19,9 @@ extern "C" void mi3d_dev_set(int i, int v) { if (i >= 0 && i < 32) mi3d_dev_tuna
 """
 
 
-def build():
+def build(out=OUT, defines=()):
+    """`defines`: extra -D options, e.g. ("-DMI3D_REDUCE_U=16",) -> a variant library for an A/B across two processes
+    (python tools/build_dev.py tools/bin/libmi3d_dev_u16.so -DMI3D_REDUCE_U=16)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
     objs = []
@@ -27,14 +29,18 @@ def build():
     open(dev_src, "w").write(DEV_UNIT)
     for name, extra in UNITS + [(dev_src, [])]:
         src = name if os.path.isabs(name) else os.path.join(CSRC, name)
-        obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        tag = "" if not defines else "_" + "".join(c for c in "".join(defines) if c.isalnum())
+        obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + tag + ".o")
         lang = ["-x", "hip"] if src.endswith(".cpp") else []
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMI3D_DEV", *extra, *lang,
-                               "-c", src, "-o", obj])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMI3D_DEV", *defines, *extra,
+                               *lang, "-c", src, "-o", obj])
         objs.append(obj)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT])
-    return OUT
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    return out
 
 
 if __name__ == "__main__":
-    print(build())
+    if len(sys.argv) > 1:
+        print(build(os.path.abspath(sys.argv[1]), tuple(sys.argv[2:])))
+    else:
+        print(build())
