@@ -352,3 +352,23 @@ def test_autograd_grad_is_never_deferred(cuda):
     assert float(outs[0].abs().max()) > 0
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max())
     assert grid_ops.DEFER_POINT0
+
+
+def test_reference_schedule_does_not_grow_memory_and_parks_nothing_across_steps(cuda):
+    """Thirty steps of the reference's two-backward schedule (the deferred point-0 scatter in every one of them): nothing
+    stays parked on encoder.params once a step is over, the allocator's live bytes are flat from step 5 on, and the
+    parameters keep moving."""
+    from mi3d import sds_step
+    opt, model, optimizer, scaler, (ro, rd, ds) = _setup(cuda, fp16=True, init_scale=8.0)
+    guidance = _TinyGuidance(cuda, deterministic=True)
+    text_z = torch.randn(2, 77, 64, generator=torch.Generator().manual_seed(1)).to(cuda)
+    live, before = [], model.encoder.params.detach().clone()
+    for it in range(30):
+        sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, 32, 32, opt,
+                                sds_backward="reference", t=500)
+        assert not model.encoder.params.__dict__.get("_mi3d_pending")
+        torch.cuda.synchronize()
+        live.append(torch.cuda.memory_allocated(cuda))
+    assert max(live[5:]) - min(live[5:]) <= 8 << 20, live          # (the sample count moves a little from step to step)
+    assert torch.isfinite(model.encoder.params).all()
+    assert float((model.encoder.params - before).abs().max()) > 0
