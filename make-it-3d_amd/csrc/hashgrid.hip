@@ -827,6 +827,11 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 //                         64-bit fixed point (LDS fp32 atomics retire 0.38 lanes/clk/CU, 64-bit integer ones 5.3:
 //                         profiles/lds_atomics_r01.txt), then adds the 64 KB tile to the gradient table.
 // Samples are processed in slices so the record arena (caller-provided workspace) stays bounded.
+// Round 4 (DESIGN.md 3.2'): under autocast the pair records take 12 bytes (Row12: the raw binary16 pair + 23-bit fixed-point
+// weights, mi3d_common.h); a second gradient pair for stencil point 0 - what an earlier backward pass through the same
+// forward left behind - rides along (mi3d_grid_scatter_binned_plus); the coarse role sends a +-eps neighbour that left the
+// base cell through a shared-face pass (face_pass: the near face into the register sums, the four far corners through the
+// gather table); level 7 (cells of 3.9 marching steps at C2) is a record level now (merge_steps).
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
 constexpr uint32_t kEmitWavesMax = 1536;
 constexpr uint32_t kReduceWavesC = 16;  // waves of a reduce workgroup (= kReduceWaves below)
