@@ -1433,7 +1433,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
                     const uint32_t excl = incl - cnt;
                     cursor[lane] = excl;
-                    gdelta[lane] = g - excl;
+                    // binary16 records: the slot's index within the LEVEL's regions of this wave, bin base included - and a
+                    // vote whether every bin's run fits its region, so that the flush of a chunk that fits (all but a
+                    // skewed tile's) stores without a bound check and a multiply per record
+                    const bool all_fit = __ballot(lane < (int)level_bins(L) && g + cnt > cap) == 0ull;
+                    gdelta[lane] = (HP ? __umul24((uint32_t)lane, cap) : 0u) + g - excl;
                     if (cnt) fill_l[lane] = g + cnt;
                     hist[lane] = 0u;
                     __builtin_amdgcn_wave_barrier();
@@ -1446,6 +1450,8 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         if (cpm[c]) {
                             const float gy = 1.0f - cfy[c], gz = 1.0f - cfz[c];
                             const uint32_t t = L.hashed ? (uint32_t)__builtin_ctz(~ccx[c]) + 1u : 0u;
+                            const uint32_t fq = HP ? fix23(cfx[c]) : 0u;   // (per point, not per record)
+                            const uint32_t hdr_pt = (t << 13) | ((fq >> 16) << 25), lo_pt = (fq & 0xFFFFu) << 16;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
                                 if ((cpm[c] >> j) & 1u) {
@@ -1453,8 +1459,9 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                                     const float w = ((j & 1u) ? cfy[c] : gy) * ((j >> 1) ? cfz[c] : gz);
                                     const uint32_t pos = atomicAdd(&cursor[e0 >> kBinShift], 1u);
                                     if (HP) {   // Row12 + the bin in the fourth word (the staging slot stays 16 bytes: one LDS write)
-                                        const Row12 r = pack_row12(e0 & (kBinEntries - 1u), t, w, cfx[c], craw0[c]);
-                                        stage[pos] = make_uint4(r.w0, r.w1, r.w2, e0 >> kBinShift);
+                                        const uint32_t wq = fix23(w);   // (pack_row12, with the point's share hoisted)
+                                        stage[pos] = make_uint4((e0 & (kBinEntries - 1u)) | hdr_pt | ((wq >> 16) << 18), craw0[c],
+                                                                (wq & 0xFFFFu) | lo_pt, e0 >> kBinShift);
                                     } else
                                     stage[pos] = make_uint4(e0 | (t << kRowEntryBits), __float_as_uint(w * cd0[c]),
                                                             __float_as_uint(w * cd1[c]), __float_as_uint(cfx[c]));
@@ -1470,7 +1477,15 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     for (uint32_t i = lane; i < total; i += kWave) {
                         const uint4 rec = stage[i];
                         if (HP) {
-                            const uint32_t bin = rec.w, slot = i + gdelta[bin];
+                            const uint32_t bin = rec.w, at = i + gdelta[bin];   // = bin * cap + slot
+                            if (all_fit) {
+#ifdef MI3D_DEV
+                                if (!(fine_level_major & 0x800u))
+#endif
+                                region12[at] = Row12{rec.x, rec.y, rec.z};
+                                continue;
+                            }
+                            const uint32_t slot = at - __umul24(bin, cap);
                             if (slot < cap) {
 #ifdef MI3D_DEV  // tools build: 0x800 = the records are sorted but not stored (timing only)
                                 if (!(fine_level_major & 0x800u))

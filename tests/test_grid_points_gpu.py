@@ -216,6 +216,34 @@ def test_binned_scatter_with_a_second_pair_for_point_0(cuda, oracle, half, works
                                  extra0=T(eplanes.astype(np.float16 if not half else np.float32), cuda))
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_binned_scatter_when_the_regions_overflow(cuda, oracle, half):
+    """A skewed problem - 30 000 samples inside one cell of the finest level, all 13 stencil offsets zero - sends every
+    record of a level to the same four bins: the (wave, bin) regions, sized for the uniform share, overflow by an order of
+    magnitude.  A full region is not an error: what does not fit goes to the table with float atomics (the sorted flush's
+    per-chunk vote, the direct appends and the coarse role's records all have that path).  Same gradient as the oracle."""
+    from mi3d import field_ops
+    rng = np.random.default_rng(23)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=cfg.n_levels, base_resolution=cfg.base_resolution, per_level_scale=cfg.per_level_scale,
+                log2_hashmap_size=cfg.log2_hashmap_size)
+    n, P = 30000, 13
+    x = (np.array([0.31, -0.22, 0.47], np.float32) + rng.uniform(-1e-4, 1e-4, (n, 3)).astype(np.float32)).astype(np.float32)
+    offs = np.zeros((P, 3), np.float32)
+    dt = np.float16 if half else np.float32
+    dout = rng.normal(size=(n, P, 16, 2)).astype(dt)
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
+    with record_scatter_workspaces() as arenas:
+        g = field_ops.scatter_binned(T(x, cuda), None, offs, P, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params).cpu().numpy()
+    assert len(arenas) == 1 and arenas[0] > 0
+    h01 = ((x + np.float32(1.0)) / np.float32(2.0)).astype(np.float32)
+    ref = oracle.hashgrid_backward(h01, dout.astype(np.float32).sum(1).reshape(n, 32), cfg)   # 13 identical points
+    scale = np.abs(ref).max()
+    # (float atomics in arrival order: 390 000 contributions of O(1) per entry - the reference's own summation noise)
+    assert np.abs(g - ref).max() <= 2e-4 * scale
+    assert np.array_equal(g != 0, ref != 0)
+
+
 def test_field_stencil_node_equals_layer_composition(cuda, oracle):
     """The fused autograd node (encode + MLP, binned scatter) against the per-layer composition on the same inputs."""
     from mi3d import field_ops, grid_ops, mlp_ops
