@@ -83,6 +83,24 @@ def main():
             ballast.pop()
             torch.cuda.empty_cache()
     res["fresh_allocations_with_ballast"] = fresh
+    # physically contiguous memory (hipExtMallocWithFlags, hipDeviceMallocContiguous) against plain hipMalloc, with the
+    # ballast still live; torch does not see these bytes
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    torch.cuda.empty_cache()
+    direct = []
+    for kind, flags in (("hipMalloc", None), ("contiguous", 0x4), ("hipMalloc", None), ("contiguous", 0x4)):
+        ptr = C.c_void_p()
+        err = hip.hipMalloc(C.byref(ptr), arena_bytes) if flags is None else hip.hipExtMallocWithFlags(C.byref(ptr), arena_bytes, flags)
+        if err != 0 or not ptr.value:
+            direct.append({"kind": kind, "error": int(err)})
+            continue
+        direct.append({"kind": kind, "ptr_mod_1GiB": ptr.value % gib, "ms": timed(ptr.value)})
+        torch.cuda.synchronize()
+        hip.hipFree(ptr)
+    res["direct_hip_allocations"] = direct
     print(json.dumps(res, indent=1))
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
