@@ -22,7 +22,7 @@ UNITS = [
     ("optim.hip", ["-ffp-contract=off"]),
     ("raster.hip", ["-ffp-contract=off"]),
 ]
-HEADERS = ["mi3d_common.h", "mi3d_grid.h", "mi3d_dev.h", os.path.join("..", "..", "include", "mi3d.h")]
+HEADERS = ["mi3d_common.h", "mi3d_grid.h", "mi3d_dev.h", "lds_transpose.h", os.path.join("..", "..", "include", "mi3d.h")]
 
 
 def _newer(src, dst):

@@ -27,6 +27,13 @@
 
 #include "../../include/mi3d.h"
 #include "mi3d_dev.h"
+#include "lds_transpose.h"
+
+// 1: the backward turns its binary16 tiles round through LDS (ds_read_b64_tr_b16, csrc/lds_transpose.h); 0: on the matrix
+// core, as a product with an identity block (round 3)
+#ifndef MI3D_MLP_LDS_TRANSPOSE
+#define MI3D_MLP_LDS_TRANSPOSE 1
+#endif
 
 namespace {
 
@@ -50,6 +57,7 @@ __device__ __forceinline__ int rowmap(int q, int h) { return (q & 3) + 8 * (q >>
 struct F16 {
     using elem = _Float16;
     static constexpr int kUnits = 2;  // 16-byte vectors per lane per K-block (8 halfs each)
+    static constexpr bool kLdsTranspose = MI3D_MLP_LDS_TRANSPOSE != 0;
     struct KB { half8 v[2]; };
     __device__ static __forceinline__ float round(float x) { return (float)(_Float16)x; }
     __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q >> 3][q & 7] = (_Float16)x; }
@@ -142,6 +150,7 @@ struct F16 {
 struct F32 {
     using elem = float;
     static constexpr int kUnits = 4;  // 4 floats each
+    static constexpr bool kLdsTranspose = false;  // (the transposing LDS read moves 16-bit values)
     struct KB { float v[16]; };
     __device__ static __forceinline__ float round(float x) { return x; }
     __device__ static __forceinline__ void set(KB &k, int q, float x) { k.v[q] = x; }
@@ -1018,12 +1027,28 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         return P::load_block(lds + (size_t)b * block_bytes<P>(), l);
     };
     auto bias = [&](int tile) { return bias_tile(biasT, tile, ht); };
-    // a tile held "lane = sample" times an identity block = the same tile held "lane = index" (exact: one non-zero
-    // product per output)
+    // A tile held "lane = sample" -> the same tile held "lane = index".  Binary16 tiles go through the wave's own 2.25 KB
+    // of LDS (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per lane, csrc/lds_transpose.h): bit moves.  Otherwise (exact fp32)
+    // the tile times an identity block on the matrix core (exact: one non-zero product per output).
+    [[maybe_unused]] mi3d_tr::lds_ptr tr_wr_d = nullptr, tr_wr_x = nullptr, tr_rd = nullptr;
+    if constexpr (P::kLdsTranspose) {
+        mi3d_tr::lds_ptr tile = mi3d_tr::to_lds(biasT + B::BIAS_TILES * 32) + (threadIdx.x / kWave) * mi3d_tr::kTileBytes;
+        tr_wr_d = tile + mi3d_tr::write_offset_d(lane);
+        tr_wr_x = tile + mi3d_tr::write_offset_x(lane);
+        tr_rd = tile + mi3d_tr::read_offset(lane);
+    }
     auto transpose = [&](const KB &a, int id_block) {
-        f32x16 t = splat(0.f);
-        P::mma(t, a, blk_fresh(id_block));
-        return P::cast(t);
+        if constexpr (P::kLdsTranspose) {
+            KB r;
+            if (id_block == B::IDX) mi3d_tr::write_tile<true>(tr_wr_x, a.v[0], a.v[1]);   // (a constant at every call)
+            else mi3d_tr::write_tile<false>(tr_wr_d, a.v[0], a.v[1]);
+            mi3d_tr::read_tile(tr_rd, r.v[0], r.v[1]);
+            return r;
+        } else {
+            f32x16 t = splat(0.f);
+            P::mma(t, a, blk_fresh(id_block));
+            return P::cast(t);
+        }
     };
     const uint32_t last_plane = din / 2 - 1;
 
@@ -1061,8 +1086,10 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         const KB dO = dout_kb<P>(dor, valid && h == 0);
         if (tile + n_waves < n_tiles) {
             const size_t rn = ((size_t)tile + n_waves) * 32 + p;
-            if constexpr (HP) load_rows_half_g(x, rn, n, h, xp, last_plane, rawh);
-            else load_rows_raw_g(x, rn, n, h, xp, din, raw);
+            // (LDS transposes: the eight 64-bit plane indices of the prefetch are formed here from the laundered lane
+            // half instead of living across the tile as lane constants - they were what spilled, 20 registers)
+            if constexpr (HP) load_rows_half_g(x, rn, n, P::kLdsTranspose ? ht : h, xp, last_plane, rawh);
+            else load_rows_raw_g(x, rn, n, P::kLdsTranspose ? ht : h, xp, din, raw);
             dor = load_dout_raw(dout, rn, n);
         }
         // ---- forward recompute, lane = sample (the activations double as their own ReLU masks).  The order below keeps
@@ -1384,8 +1411,9 @@ HeadArgs make_head_args(const float *x, const float *x2, const float *offsets_ho
 template <class P> constexpr size_t lds_bytes(int n_blocks) {
     return (size_t)n_blocks * block_bytes<P>() + (HID + HID + 32) * sizeof(float);
 }
-template <class P> constexpr size_t lds_bytes_g(int n_blocks, int bias_tiles) {
-    return (size_t)n_blocks * block_bytes<P>() + (size_t)bias_tiles * 32 * sizeof(float);
+template <class P> constexpr size_t lds_bytes_g(int n_blocks, int bias_tiles, bool transposes = false) {
+    return (size_t)n_blocks * block_bytes<P>() + (size_t)bias_tiles * 32 * sizeof(float) +
+           (transposes && P::kLdsTranspose ? (size_t)kWavesPerWG * mi3d_tr::kTileBytes : 0u);
 }
 
 int grid_for(uint32_t n, int wgs_per_cu) {
@@ -1412,7 +1440,7 @@ void launch_bwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, co
                 const Weights &w, float *dx, uint32_t dx_planes, const Grads &g) {
     using B = Blk<NTH, LAYERS>;
     hipLaunchKernelGGL((k_mlp_bwd_g<P, NTH, LAYERS, HP>), grid, dim3(kWave * kWavesPerWG),
-                       lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
+                       lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES, true), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
 }
 // runtime (hidden width, layer count) -> the template instance
 #define MI3D_MLP_DISPATCH(FN, P, HP, nth, layers, ...)                     \

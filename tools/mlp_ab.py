@@ -1,0 +1,115 @@
+"""A/B of the MLP backward across two builds of the library IN ONE PROCESS (both loaded with ctypes, same inputs, same
+box): timings at the headline size and equality of everything the kernel writes, for every template instance.
+
+    python tools/build_dev.py tools/bin/libmi3d_dev_tr0.so -DMI3D_MLP_LDS_TRANSPOSE=0
+    python tools/build_dev.py tools/bin/libmi3d_dev_tr1.so -DMI3D_MLP_LDS_TRANSPOSE=1
+    python tools/mlp_ab.py --a tools/bin/libmi3d_dev_tr0.so --b tools/bin/libmi3d_dev_tr1.so --out gpurun_out/mlp_ab.json
+
+The input gradient planes must be EQUAL as numbers (a transposition moves values; -0.0 against +0.0 is the one
+difference the two ways of turning a tile may leave, and the scatter skips both); the weight gradients agree to the
+order their float atomics landed in.  Exit code 1 if they do not."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "make-it-3d_amd"))
+
+
+def load(path):
+    from mi3d import _lib as L
+    lib = C.CDLL(os.path.abspath(path))
+    for name in ("mi3d_mlp_backward", "mi3d_mlp_forward"):
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = L._SIGNATURES[name], C.c_int
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--a", required=True)
+    ap.add_argument("--b", required=True)
+    ap.add_argument("--rows", type=int, default=13 * 10_878_976)  # the headline's evaluations per step
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--out", default="gpurun_out/mlp_ab.json")
+    a = ap.parse_args()
+    from mi3d import _lib as L
+    libs = {"a": load(a.a), "b": load(a.b)}
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = {"a": a.a, "b": a.b, "cases": []}
+    ok = True
+
+    def case(rows, din, hid, layers, half_planes, half_mode, time_it):
+        nonlocal ok
+        pdt = torch.float16 if half_planes else torch.float32
+        feats = (torch.randn(din // 2, rows, 2, device=dev, generator=g) * 0.5).to(pdt)
+        dh = torch.randn(rows, 4, device=dev, generator=g)
+        dims = [(hid, din)] + ([(hid, hid)] if layers == 3 else []) + [(4, hid)]
+        ws = []
+        for (o, i) in dims:
+            ws += [torch.randn(o, i, device=dev, generator=g) * (2.0 / i) ** 0.5, torch.randn(o, device=dev, generator=g) * 0.1]
+        if layers == 2:
+            ws = ws[:2] + [None, None] + ws[2:]
+        out = {}
+        for k, lib in libs.items():
+            dplanes = torch.full((din // 2, rows, 2), float("nan"), device=dev, dtype=pdt)
+            grads = [torch.zeros_like(t) if t is not None else None for t in ws]
+
+            def run():
+                err = lib.mi3d_mlp_backward(L.ptr(feats), rows, int(half_planes), L.ptr(dh), rows, *[L.ptr(t) for t in ws], din, hid, 4,
+                                            int(half_mode), L.ptr(dplanes), rows, *[L.ptr(t) for t in grads], st())
+                if err:
+                    raise RuntimeError(f"mi3d_mlp_backward: hipError {err}")
+            run()
+            torch.cuda.synchronize()
+            ms = None
+            if time_it:
+                keep = [t.clone() if t is not None else None for t in grads]
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(a.iters):
+                    run()
+                ev[1].record()
+                torch.cuda.synchronize()
+                ms = ev[0].elapsed_time(ev[1]) / a.iters
+                grads = keep
+            out[k] = (dplanes, grads, ms)
+        da, db = out["a"][0], out["b"][0]
+        same = bool((da == db).all()) and not bool(torch.isnan(da.float()).any())
+        bit_same = bool((da.view(torch.int16 if half_planes else torch.int32) == db.view(torch.int16 if half_planes else torch.int32)).all())
+        werr = 0.0
+        for x, y in zip(out["a"][1], out["b"][1]):
+            if x is not None:
+                werr = max(werr, float((x - y).abs().max() / x.abs().max().clamp_min(1e-30)))
+        rec = {"rows": rows, "din": din, "hidden": hid, "layers": layers, "half_planes": half_planes, "half_mode": half_mode,
+               "dx_equal": same, "dx_bit_identical": bit_same, "weight_grad_max_rel_diff": werr,
+               "dx_nonzero_fraction": float((da != 0).float().mean()), "a_ms": out["a"][2], "b_ms": out["b"][2]}
+        ok = ok and same and werr < 1e-4
+        res["cases"].append(rec)
+        print(json.dumps(rec), flush=True)
+        del out, da, db, feats, dh
+        torch.cuda.empty_cache()
+
+    # every template instance of k_mlp_bwd_g (hidden 32 / 64 x 2 / 3 layers x plane type), ragged row counts, narrow inputs
+    for hid in (64, 32):
+        for layers in (3, 2):
+            for half_planes, half_mode in ((True, True), (False, True), (False, False)):
+                for din, rows in ((32, 1_000_003), (14, 50_001)):
+                    case(rows, din, hid, layers, half_planes, half_mode, False)
+    case(a.rows, 32, 64, 3, True, True, True)   # the headline: 13 points x 10.9 M samples, binary16 planes
+    case(a.rows // 13, 32, 64, 3, True, True, True)   # the point-0 pass
+    res["ok"] = ok
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+    print("MLP_AB", "OK" if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
