@@ -29,9 +29,13 @@ def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, defines=()):
+    """`out` / `defines`: a product-grade VARIANT library (same flags plus -D options) beside libmi3d.so, for an A/B of two
+    product builds on the GPU box; its objects live in their own directory.  Without them: libmi3d.so."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    tag = "".join(c for c in "".join(defines) if c.isalnum())
+    objdir = os.path.join(CSRC, "build" + ("_" + tag if tag else ""))
+    OUT = out or globals()["OUT"]
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, rebuilt = [], False
@@ -41,7 +45,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, name.replace(".hip", ".o"))
         if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs if os.path.exists(h)):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", *extra, "-c",
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", *defines, *extra, "-c",
                    src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

@@ -34,6 +34,14 @@
 #ifndef MI3D_MLP_LDS_TRANSPOSE
 #define MI3D_MLP_LDS_TRANSPOSE 1
 #endif
+// development switches of the backward (variant builds, tools/build_dev.py): an instance of its own for the full input
+// width; the next tile's rows requested late in the tile (after the last use of this tile's) instead of at its top
+#ifndef MI3D_MLP_BWD_FULL
+#define MI3D_MLP_BWD_FULL 0
+#endif
+#ifndef MI3D_MLP_BWD_LATE_PREFETCH
+#define MI3D_MLP_BWD_LATE_PREFETCH 0
+#endif
 
 namespace {
 
@@ -108,17 +116,21 @@ struct F16 {
     __device__ static __forceinline__ KB masked(const f32x16 &d, const KB &act) {
         KB k;
         const unsigned ones = 0x00010001u;
+        using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;   // (whole registers in and out: see sum())
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x2 pr = {d[2 * j], d[2 * j + 1]};
-            const half2v hv = __builtin_convertvector(pr, half2v);
-            const half2v av = {act.v[j >> 2][2 * (j & 3)], act.v[j >> 2][2 * (j & 3) + 1]};
-            unsigned m = __builtin_bit_cast(unsigned, av), dv = __builtin_bit_cast(unsigned, hv);
-            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %3"
-                : "=&v"(m) : "v"(m), "s"(ones), "v"(dv));
-            const half2v r = __builtin_bit_cast(half2v, m);
-            k.v[j >> 2][2 * (j & 3)] = r[0];
-            k.v[j >> 2][2 * (j & 3) + 1] = r[1];
+        for (int u = 0; u < 2; ++u) {
+            const u32x4 aw = __builtin_bit_cast(u32x4, act.v[u]);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 pr = {d[8 * u + 2 * j], d[8 * u + 2 * j + 1]};
+                const unsigned dv = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, half2v));
+                unsigned m = aw[j];
+                asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %3"
+                    : "=&v"(m) : "v"(m), "s"(ones), "v"(dv));
+                o[j] = m;
+            }
+            k.v[u] = __builtin_bit_cast(half8, o);
         }
         return k;
     }
@@ -138,10 +150,14 @@ struct F16 {
     __device__ static __forceinline__ float sum(const KB &k) {
         float s = 0.f;
         const half2v ones = {(_Float16)1, (_Float16)1};
+        // (whole registers: picking the two halves of a pair out of the vector and putting them together again made
+        // hipcc emit a v_bfi copy in front of 6 of every 8 dot products - 30 of the backward's ~360 VALU instructions)
+        using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const half2v pr = {k.v[j >> 2][2 * (j & 3)], k.v[j >> 2][2 * (j & 3) + 1]};
-            s = __builtin_amdgcn_fdot2(pr, ones, s, false);
+        for (int u = 0; u < 2; ++u) {
+            const u32x4 w = __builtin_bit_cast(u32x4, k.v[u]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[j]), ones, s, false);
         }
         return s;
     }
@@ -891,9 +907,16 @@ __device__ __forceinline__ f32x16 bias_tile(const float *biasT, int tile, int h)
 
 // Rows of a tile for input width din <= 32.  Planes / features past din are read from the last valid one instead of
 // being predicated off (their weights are zero, so whatever finite value they carry contributes nothing).
+template <bool FULL = false>
 __device__ __forceinline__ void load_rows_half_g(const float *__restrict__ x, size_t row, size_t n, int h,
                                                  size_t plane_rows, uint32_t last_plane, uint32_t (&u)[8]) {
     row = row < n ? row : n - 1;
+    if constexpr (FULL) {   // all 16 planes: ONE 64-bit lane address, the planes a uniform stride apart
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(x) + ((size_t)(8 * h) * plane_rows + row);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = src[(size_t)j * plane_rows];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t pl = (uint32_t)(8 * h + j) < last_plane ? (uint32_t)(8 * h + j) : last_plane;
@@ -1002,7 +1025,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_fwd_g(const float
     }
 }
 
-template <class P, int NTH, int LAYERS, bool HP>
+template <class P, int NTH, int LAYERS, bool HP, bool FULL>   // FULL: dim_in = 32 (plane indices and store guards constant)
 __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float *__restrict__ x, uint32_t x_planes,
                                                                         const float *__restrict__ dout, uint32_t n,
                                                                         uint32_t din, Weights w, float *__restrict__ dx,
@@ -1050,7 +1073,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
             return P::cast(t);
         }
     };
-    const uint32_t last_plane = din / 2 - 1;
+    const uint32_t last_plane = FULL ? (uint32_t)(DIN / 2 - 1) : din / 2 - 1;
 
     // weight-gradient tiles: lane = column (input-side feature), register q = row rowmap(q, h) (output-side feature)
     f32x16 gW1[NTH], gW2[NTH][NTH], gW3[NTH];
@@ -1069,7 +1092,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
     f32x4 dor;
     {
         const size_t r0 = (size_t)wave * 32 + p;
-        if constexpr (HP) load_rows_half_g(x, r0, n, h, x_planes, last_plane, rawh);
+        if constexpr (HP) load_rows_half_g<FULL && P::kLdsTranspose>(x, r0, n, h, x_planes, last_plane, rawh);
         else load_rows_raw_g(x, r0, n, h, x_planes, din, raw);
         dor = load_dout_raw(dout, r0, n);
     }
@@ -1084,14 +1107,18 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         if constexpr (HP) X = rows_kb_half<P>(rawh);
         else X = rows_kb<P>(raw);
         const KB dO = dout_kb<P>(dor, valid && h == 0);
-        if (tile + n_waves < n_tiles) {
-            const size_t rn = ((size_t)tile + n_waves) * 32 + p;
-            // (LDS transposes: the eight 64-bit plane indices of the prefetch are formed here from the laundered lane
-            // half instead of living across the tile as lane constants - they were what spilled, 20 registers)
-            if constexpr (HP) load_rows_half_g(x, rn, n, P::kLdsTranspose ? ht : h, xp, last_plane, rawh);
-            else load_rows_raw_g(x, rn, n, P::kLdsTranspose ? ht : h, xp, din, raw);
-            dor = load_dout_raw(dout, rn, n);
-        }
+        auto prefetch = [&]() {
+            if (tile + n_waves < n_tiles) {
+                const size_t rn = ((size_t)tile + n_waves) * 32 + p;
+                // (LDS transposes: the eight 64-bit plane indices of the prefetch are formed here from the laundered lane
+                // half instead of living across the tile as lane constants - they were what spilled, 20 registers)
+                if constexpr (HP) load_rows_half_g<FULL && P::kLdsTranspose>(x, rn, n, P::kLdsTranspose ? ht : h, xp, last_plane, rawh);
+                else load_rows_raw_g(x, rn, n, P::kLdsTranspose ? ht : h, xp, din, raw);
+                dor = load_dout_raw(dout, rn, n);
+            }
+        };
+        constexpr bool late_prefetch = P::kLdsTranspose && HP && MI3D_MLP_BWD_LATE_PREFETCH != 0;
+        if constexpr (!late_prefetch) prefetch();
         // ---- forward recompute, lane = sample (the activations double as their own ReLU masks).  The order below keeps
         // the live set small (it is what decides spills at 256 registers): every orientation-1 tile is transposed
         // as soon as its last orientation-1 use is over, and the hidden-1 gradient is formed directly in orientation 2,
@@ -1161,6 +1188,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         }
         {   // dW1[i][j] += sum_s dH1[s][i] X[s][j]
             const KB Xp = transpose(X, B::IDX);
+            if constexpr (late_prefetch) prefetch();   // (this tile's rows are dead: the next tile's land in their registers)
 #pragma unroll
             for (int t = 0; t < NTH; ++t) {
                 gb1[t] += P::sum(dH1p[t]);
@@ -1174,7 +1202,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
                 const KB dH1 = LAYERS == 3 ? transpose(dH1p[tk], B::IDD) : dHL[tk];
                 P::mma(acc, blk(B::W1T + tk), dH1);
             }
-            const bool full = din == (uint32_t)DIN;  // uniform: the usual width stores without per-plane guards
+            const bool full = FULL || din == (uint32_t)DIN;  // uniform: the usual width stores without per-plane guards
             if constexpr (HP) {
             if (valid) {
                 // binary16 planes: one 4-byte store per (level, row); this IS the rounding torch.autocast gives the
@@ -1186,7 +1214,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
                     pk[2 * c] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){acc[4 * c], acc[4 * c + 1]}, half2v));
                     pk[2 * c + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){acc[4 * c + 2], acc[4 * c + 3]}, half2v));
                 }
-                if (full) {
+                if (FULL && P::kLdsTranspose) {
+                    uint32_t *dst = dxh + (size_t)(2 * h) * dxp;   // one lane address; the planes a uniform stride apart
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dst[(size_t)(4 * c) * dxp] = pk[2 * c];
+                        dst[(size_t)(4 * c + 1) * dxp] = pk[2 * c + 1];
+                    }
+                } else if (full) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         dxh[(size_t)(4 * c + 2 * h) * dxp] = pk[2 * c];
@@ -1439,8 +1474,13 @@ template <class P, int NTH, int LAYERS, bool HP>
 void launch_bwd(dim3 grid, hipStream_t st, const float *x, uint32_t x_planes, const float *dout, uint32_t n, uint32_t din,
                 const Weights &w, float *dx, uint32_t dx_planes, const Grads &g) {
     using B = Blk<NTH, LAYERS>;
-    hipLaunchKernelGGL((k_mlp_bwd_g<P, NTH, LAYERS, HP>), grid, dim3(kWave * kWavesPerWG),
-                       lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES, true), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
+    // (binary16 planes at the full input width get their own instance: constant plane indices, no store guards)
+    if (MI3D_MLP_BWD_FULL != 0 && HP && P::kLdsTranspose && din == (uint32_t)DIN)
+        hipLaunchKernelGGL((k_mlp_bwd_g<P, NTH, LAYERS, HP, MI3D_MLP_BWD_FULL != 0 && HP && P::kLdsTranspose>), grid, dim3(kWave * kWavesPerWG),
+                           lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES, true), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
+    else
+        hipLaunchKernelGGL((k_mlp_bwd_g<P, NTH, LAYERS, HP, false>), grid, dim3(kWave * kWavesPerWG),
+                           lds_bytes_g<P>(B::ALL_COUNT, B::BIAS_TILES, true), st, x, x_planes, dout, n, din, w, dx, dx_planes, g);
 }
 // runtime (hidden width, layer count) -> the template instance
 #define MI3D_MLP_DISPATCH(FN, P, HP, nth, layers, ...)                     \
