@@ -37,10 +37,10 @@
 // development switches of the backward (variant builds, tools/build_dev.py): an instance of its own for the full input
 // width; the next tile's rows requested late in the tile (after the last use of this tile's) instead of at its top
 #ifndef MI3D_MLP_BWD_FULL
-#define MI3D_MLP_BWD_FULL 0
+#define MI3D_MLP_BWD_FULL 1
 #endif
 #ifndef MI3D_MLP_BWD_LATE_PREFETCH
-#define MI3D_MLP_BWD_LATE_PREFETCH 0
+#define MI3D_MLP_BWD_LATE_PREFETCH 1
 #endif
 
 namespace {
@@ -157,7 +157,10 @@ struct F16 {
         for (int u = 0; u < 2; ++u) {
             const u32x4 w = __builtin_bit_cast(u32x4, k.v[u]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[j]), ones, s, false);
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t wj = w[j];   // (a copy first: __builtin_bit_cast of the vector ELEMENT w[j] reads element 0 - hipcc 7.2)
+                s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, wj), ones, s, false);
+            }
         }
         return s;
     }
