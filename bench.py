@@ -647,9 +647,10 @@ def main():
                  "SDS pass (nerf/sd.py:171) reaches stencil point 0 only, its gradient planes are parked and ride along in "
                  "the regulariser pass's 13-point scatter (mi3d.grid_ops.DEFER_POINT0)",
                  "scatter_binned", work_of=scatter_work),
-            roof("k_mlp_forward<F16>", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
+            roof("k_mlp_fwd_g<F16, 2, 3, binary16 planes> (csrc/field.hip)", "mlp_fwd", 12800.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
                  "streams 64 B of binary16 planes in + 16 B out per evaluation (fp32 planes without autocast: 128 B)", "k_mlp_forward"),
-            roof("k_mlp_backward<F16> (recompute + dgrad + wgrad in one kernel)", "mlp_bwd",
+            roof("k_mlp_bwd_g<F16, 2, 3, binary16 planes, full width> (recompute + dgrad + wgrad in one kernel; the tiles of the weight "
+                 "gradients turned round through LDS, ds_read_b64_tr_b16; csrc/field.hip)", "mlp_bwd",
                  25600.0, "mfma", MFMA_F16_PEAK_TFLOPS, "TFLOP/s",
                  "80 B read + 64 B written per evaluation with binary16 planes", "k_mlp_backward"),
         ]
