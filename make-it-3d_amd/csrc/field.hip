@@ -833,7 +833,15 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, WPS) void k_mlp_backward(const 
 // products, and the operands of the weight gradients (which need "lane = feature, registers = samples") come from
 // TRANSPOSING the orientation-1 tiles on the matrix core (a product with an identity block: 2 MFMAs and 8 converts per
 // K-block) instead of recomputing the layers in the second orientation (4 MFMAs, 16-32 converts / masks and a bias
-// splat per K-block): 61 MFMAs and ~520 instructions per tile.
+// splat per K-block): 61 MFMAs and 676 instructions per tile.
+//
+// Round 4: binary16 tiles are turned round through the wave's own LDS instead (ds_read_b64_tr_b16, csrc/lds_transpose.h:
+// 4 writes + 4 transposing reads per lane, nothing on the matrix core, no converts) - the kernel was issue-bound, and 20
+// of its 61 MFMAs moved bits.  43 MFMAs and ~500 instructions per tile with the instruction diet described at the
+// functions below (whole-register sums / masks, an instance of its own for the full input width, the next tile's rows
+// requested after this tile's last use of its own): 9.2-9.5 -> 8.3 ms for 141 M rows in one process
+// (tools/mlp_ab.py, profiles/mlp_ab_r04_final.json), every output of every instance bit-identical in the input
+// gradient.  The exact-fp32 kernels keep the identity product.
 template <int NTH, int LAYERS> struct Blk {
     static constexpr int W1 = 0;                                      // [tn]      as B_W1
     static constexpr int W2 = W1 + NTH;                               // [tn][tk]  as B_W2 (three layers only)

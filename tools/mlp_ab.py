@@ -1,13 +1,13 @@
-"""A/B of the MLP backward across two builds of the library IN ONE PROCESS (both loaded with ctypes, same inputs, same
-box): timings at the headline size and equality of everything the kernel writes, for every template instance.
+"""A/B of the MLP backward across several builds of the library IN ONE PROCESS (all loaded with ctypes, same inputs,
+same box): equality of everything the kernel writes, for every template instance, and timings at the headline size.
 
-    python tools/build_dev.py tools/bin/libmi3d_dev_tr0.so -DMI3D_MLP_LDS_TRANSPOSE=0
-    python tools/build_dev.py tools/bin/libmi3d_dev_tr1.so -DMI3D_MLP_LDS_TRANSPOSE=1
-    python tools/mlp_ab.py --a tools/bin/libmi3d_dev_tr0.so --b tools/bin/libmi3d_dev_tr1.so --out gpurun_out/mlp_ab.json
+    python tools/build_dev.py tools/bin/libmi3d_dev_tr0.so -DMI3D_MLP_LDS_TRANSPOSE=0      # round 3's form: the reference
+    python tools/build_dev.py tools/bin/libmi3d_dev_f1l1.so -DMI3D_MLP_BWD_FULL=1 -DMI3D_MLP_BWD_LATE_PREFETCH=1
+    python tools/mlp_ab.py --libs tools/bin/libmi3d_dev_tr0.so,tools/bin/libmi3d_dev_f1l1.so --out gpurun_out/mlp_ab.json
 
-The input gradient planes must be EQUAL as numbers (a transposition moves values; -0.0 against +0.0 is the one
-difference the two ways of turning a tile may leave, and the scatter skips both); the weight gradients agree to the
-order their float atomics landed in.  Exit code 1 if they do not."""
+The input gradient planes must be EQUAL as numbers to the first library's (a transposition moves values; -0.0 against
++0.0 is the one difference the two ways of turning a tile may leave, and the scatter skips both); the weight gradients
+agree to the order their float atomics landed in (1e-4 relative).  Exit code 1 if they do not."""
 import argparse
 import ctypes as C
 import json
