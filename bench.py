@@ -26,7 +26,9 @@ The JSON line also carries
   roofline     : the step's dominant kernel - algorithmic bytes per launch (1024 B per field evaluation
                  gathered, 2048 B read-modify-written by the scatter) over its launch duration measured with HIP events
                  on the launch stream during the timed steps; the other hot kernels under rooflines_other; `traffic` =
-                 HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r02.json);
+                 HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command's --profile-run
+                 (profiles/pmc_r04.json; a counter pass wraps the process from outside and costs a run of its own, so it
+                 cannot be taken inside the timed process: `traffic_source` says which file and how it was collected);
   cpu_baseline : the reference's own pure-PyTorch renderer (nerf/renderer.py:332-479 `run` + nerf/network_tcnn.py on a
                  torch hash grid; staged sources, oracle/_ref/py) forward + backward on a bounded ray sample on this
                  box's host cores (kind "reference"); the C oracle port when the staged sources are absent ("port");
@@ -80,16 +82,16 @@ def ensure_built():
 
 
 def pmc_traffic(kernel, workload, evals):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
-    in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this run's
-    evaluation count; None if not collected."""
+    """(HBM bytes per launch, the file they come from) of `kernel`: the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
+    scaled to this run's evaluation count; (None, None) if not collected."""
     for name in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
-            return rec["hbm_bytes_per_eval"] * evals
+            return rec["hbm_bytes_per_eval"] * evals, "profiles/" + name
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def _c1_network(ref_import, device="cpu"):
@@ -613,11 +615,16 @@ def main():
             work = sum(work_of(e) for e in ev) if work_of else sum(ev) * per_eval
             a = work / t / (1e9 if bound == "hbm" else 1e12) if t > 0 else 0.0
             n_launch = max(1, len(ms.get(key, [])))
-            traffic = None
+            traffic, source = None, None
             if pmc_key is not None:
-                traffic = pmc_traffic(pmc_key, args.workload, sum(ev) / n_launch)
+                traffic, source = pmc_traffic(pmc_key, args.workload, sum(ev) / n_launch)
             return {"kernel": kernel, "bound": bound, "achieved": a, "peak": peak, "unit": unit, "frac": a / peak,
-                    "traffic": traffic, "launches": len(ms.get(key, [])), "avg_launch_ms": 1e3 * t / n_launch,
+                    "traffic": traffic,
+                    "traffic_source": (source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around `bench.py "
+                                       "--profile-run` (separate runs, averaged over the timed steps' launches, FETCH_SIZE "
+                                       "x 2, the emit's WRITE_SIZE divided by its sector calibration), scaled by this run's "
+                                       "evaluations per launch - not collected in this process") if source else None,
+                    "launches": len(ms.get(key, [])), "avg_launch_ms": 1e3 * t / n_launch,
                     "ms_per_step": 1e3 * t / args.steps,
                     "algorithmic_work_per_launch": work / n_launch, "note": note}
 
