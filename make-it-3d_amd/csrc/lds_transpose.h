@@ -20,10 +20,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mi3d_common.h"
 
 namespace mi3d_tr {
 
-constexpr int kRowBytes = 72;
+constexpr int kRowBytes = mi3d::kTrRowBytes;   // (the index math lives in mi3d_common.h, where the host tests reach it)
 constexpr int kTileBytes = 32 * kRowBytes;  // per wave
 
 using half4v = __attribute__((ext_vector_type(4))) _Float16;
@@ -38,15 +39,10 @@ __device__ __forceinline__ half4v tr_read(lds_ptr p) {
     return __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_short4_ptr>(p)));
 }
 
-// byte offsets of a lane inside its wave's tile image
-__device__ __forceinline__ uint32_t write_offset_d(int lane) { return (uint32_t)(kRowBytes * (lane & 31) + 8 * (lane >> 5)); }
-__device__ __forceinline__ uint32_t write_offset_x(int lane) { return (uint32_t)(kRowBytes * (lane & 31) + 32 * (lane >> 5)); }
-// the lane's share of the [4][16] blocks its 16-lane group reads: row 4 h' + (t >> 2) of the 8 rows of chunk c (c enters as
-// the immediate 8 kRowBytes c), features 16 (group & 1) + 4 (t & 3) ... + 3
-__device__ __forceinline__ uint32_t read_offset(int lane) {
-    const int t = lane & 15, g = lane >> 4;
-    return (uint32_t)(kRowBytes * (4 * (lane >> 5) + (t >> 2)) + 8 * (4 * (g & 1) + (t & 3)));
-}
+// byte offsets of a lane inside its wave's tile image (mi3d_common.h)
+__device__ __forceinline__ uint32_t write_offset_d(int lane) { return mi3d::tr_write_offset_d(lane); }
+__device__ __forceinline__ uint32_t write_offset_x(int lane) { return mi3d::tr_write_offset_x(lane); }
+__device__ __forceinline__ uint32_t read_offset(int lane) { return mi3d::tr_read_offset(lane); }
 
 // the lane's 16 values (two 8-value vectors, as field.hip's F16::KB holds them) into the image.  wr = tile + write_offset_*
 template <bool KIND_X>

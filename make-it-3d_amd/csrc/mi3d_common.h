@@ -219,4 +219,19 @@ MI3D_HD void unpack_row12_fields(uint32_t w0, uint32_t w2, uint32_t &e_local, ui
     fx = (float)(((w0 >> 25) << 16) | (w2 >> 16)) * kUnfix23;
 }
 
+// ---- a 32 x 32 binary16 tile turned round through LDS (field.hip's MLP backward; csrc/lds_transpose.h holds the device side) ----
+// Byte offsets of a lane inside its wave's tile image M[sample][feature]: a row = 32 features = 64 bytes, rows kTrRowBytes
+// apart.  The lane's 16 values are four 8-byte chunks; value order "D" (an MFMA output tile: value q of lane half h = index
+// (q & 3) + 8 (q >> 2) + 4 h) puts chunk c at features 8 c + 4 h, order "X" (rows as loaded: 16 h + q) at 16 h + 4 c.
+// The transposing read (ds_read_b64_tr_b16) hands lane t of a 16-lane group, value j, what lane 4 j + (t >> 2) of the group
+// loaded as its value t & 3; with the read offsets below (+ 8 kTrRowBytes c for chunk c) lane = feature gets value q =
+// sample rowmap(q, h').  tests/test_host_math.py plays this through on the host; tools/tr_probe.hip on the chip.
+constexpr int kTrRowBytes = 72;
+MI3D_HD uint32_t tr_write_offset_d(int lane) { return (uint32_t)(kTrRowBytes * (lane & 31) + 8 * (lane >> 5)); }
+MI3D_HD uint32_t tr_write_offset_x(int lane) { return (uint32_t)(kTrRowBytes * (lane & 31) + 32 * (lane >> 5)); }
+MI3D_HD uint32_t tr_read_offset(int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    return (uint32_t)(kTrRowBytes * (4 * (lane >> 5) + (t >> 2)) + 8 * (4 * (g & 1) + (t & 3)));
+}
+
 }  // namespace mi3d

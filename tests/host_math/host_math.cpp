@@ -79,4 +79,11 @@ void hm_pair_rule(const uint32_t* cell, uint32_t n, uint32_t size, uint32_t* e0,
         e1_from_rule[i] = e0[i] ^ (((t >= 32 ? 0xFFFFFFFFu : (1u << t) - 1u)) & (size - 1u));
     }
 }
+// the MLP backward's tile transposition through LDS: the three byte offsets of a lane (csrc/mi3d_common.h)
+void hm_tr_offsets(uint32_t* wr_d, uint32_t* wr_x, uint32_t* rd, int32_t* row_bytes) {
+    for (int lane = 0; lane < 64; lane++) {
+        wr_d[lane] = tr_write_offset_d(lane); wr_x[lane] = tr_write_offset_x(lane); rd[lane] = tr_read_offset(lane);
+    }
+    *row_bytes = kTrRowBytes;
+}
 }

@@ -3,7 +3,8 @@
 // 1. raw exchange pattern: halfword i of LDS holds i, lane l reads the 8 bytes at 8 l: value j of lane l must be
 //    64 (l >> 4) + 16 j + (l & 15);
 // 2. a 32 x 32 tile held "lane = sample" (both value orders) written and read back "lane = feature", bit for bit;
-// 3. what the round trip costs beside the identity product it replaces (cycles per tile of one wave, s_memtime).
+// 3. what the round trip costs beside the identity product it replaces (cycles per tile of one wave, s_memtime);
+// 4. the round trip's throughput on the whole chip against the row pitch of the tile image.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,6 +71,53 @@ __global__ void k_mfma(const _Float16 *in, _Float16 *out, int reps, long long *c
     }
 }
 
+
+// 4. throughput of the round trip on a full chip (8 waves per CU, as the MLP backward runs) against the row pitch of the
+//    tile image - what the 8 bytes of padding buy, and whether another pitch would do better
+template <int ROW>
+__global__ __launch_bounds__(256) void k_pitch(const _Float16 *in, _Float16 *out, int reps) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lds_ptr tile = to_lds(lds) + wave * (32 * ROW);
+    half8v a0, a1;
+    for (int i = 0; i < 8; ++i) { a0[i] = in[lane * 16 + i]; a1[i] = in[lane * 16 + 8 + i]; }
+    lds_ptr wr = tile + ROW * (lane & 31) + 8 * (lane >> 5);
+    const int t = lane & 15, g = lane >> 4;
+    lds_ptr rd = tile + ROW * (4 * (lane >> 5) + (t >> 2)) + 8 * (4 * (g & 1) + (t & 3));
+    for (int r = 0; r < reps; ++r) {
+        *reinterpret_cast<lds_half4_ptr>(wr + 0) = __builtin_shufflevector(a0, a0, 0, 1, 2, 3);
+        *reinterpret_cast<lds_half4_ptr>(wr + 16) = __builtin_shufflevector(a0, a0, 4, 5, 6, 7);
+        *reinterpret_cast<lds_half4_ptr>(wr + 32) = __builtin_shufflevector(a1, a1, 0, 1, 2, 3);
+        *reinterpret_cast<lds_half4_ptr>(wr + 48) = __builtin_shufflevector(a1, a1, 4, 5, 6, 7);
+        asm volatile("" ::: "memory");
+        const half4v p = tr_read(rd + 0 * 8 * ROW), q = tr_read(rd + 1 * 8 * ROW), u = tr_read(rd + 2 * 8 * ROW), v = tr_read(rd + 3 * 8 * ROW);
+        asm volatile("" ::: "memory");
+        a0 = __builtin_shufflevector(p, q, 0, 1, 2, 3, 4, 5, 6, 7);
+        a1 = __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    if (blockIdx.x == 0 && wave == 0) for (int i = 0; i < 8; ++i) { out[lane * 16 + i] = a0[i]; out[lane * 16 + 8 + i] = a1[i]; }
+}
+template <int ROW>
+static int pitch_case(const _Float16 *d_in, _Float16 *d_out) {
+    const int reps = 4001;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_pitch<ROW>, dim3(512), dim3(256), 4 * 32 * ROW, 0, d_in, d_out, 11);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_pitch<ROW>, dim3(512), dim3(256), 4 * 32 * ROW, 0, d_in, d_out, reps);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<_Float16> out(1024);
+    hipMemcpy(out.data(), d_out, 2048, hipMemcpyDeviceToHost);
+    int tb = 0;   // an odd number of transpositions of the D-order tile = one
+    for (int l = 0; l < 64; ++l) for (int q = 0; q < 16; ++q) tb += (float)out[l * 16 + q] != (float)(32 * rowmap(q, l >> 5) + (l & 31));
+    printf("row pitch %3d bytes: %.3f ms for %d round trips x 8 waves per CU = %.1f ns per round trip and CU%s\n", ROW, ms, reps,
+           ms * 1e6 / (reps * 8.0), tb ? "  WRONG RESULT" : "");
+    return tb != 0;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
 
 int main() {
@@ -115,6 +163,17 @@ int main() {
         CK(hipMemcpy(&c_mfma, d_cyc, 8, hipMemcpyDeviceToHost));
         printf("%d wave(s) on one CU, dependent chain of %d transpositions: LDS %.1f, identity MFMA %.1f counter ticks each\n", waves,
                2 * reps - 1, (double)c_lds / (2 * reps - 1), (double)c_mfma / (2 * reps - 1));
+    }
+    {   // (the D-order input of the tile test is what d_in holds after the loop above? no: reload it)
+        std::vector<_Float16> in(1024);
+        for (int l = 0; l < 64; ++l) for (int q = 0; q < 16; ++q) in[l * 16 + q] = (_Float16)(float)(32 * (l & 31) + rowmap(q, l >> 5));
+        CK(hipMemcpy(d_in, in.data(), 2048, hipMemcpyHostToDevice));
+        bad |= pitch_case<64>(d_in, d_out);
+        bad |= pitch_case<72>(d_in, d_out);
+        bad |= pitch_case<80>(d_in, d_out);
+        bad |= pitch_case<88>(d_in, d_out);
+        bad |= pitch_case<104>(d_in, d_out);
+        bad |= pitch_case<136>(d_in, d_out);
     }
     printf(bad ? "PROBE FAILED\n" : "PROBE OK\n");
     return bad;
