@@ -42,6 +42,12 @@
 #ifndef MI3D_MLP_BWD_LATE_PREFETCH
 #define MI3D_MLP_BWD_LATE_PREFETCH 1
 #endif
+// TIMING ONLY (variant builds for tools/mlp_ab.py --timing-only; the gradients are wrong with either bit): what a group of
+// the backward's vector instructions costs - 1 = no bias-gradient sums (40 dot products per tile), 2 = no ReLU masks on
+// the gradients (64 packed operations per tile)
+#ifndef MI3D_MLP_BWD_TIMING_CUT
+#define MI3D_MLP_BWD_TIMING_CUT 0
+#endif
 
 namespace {
 
@@ -1164,13 +1170,13 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         for (int t = 0; t < NTH; ++t) {
             f32x16 acc = splat(0.f);
             P::mma_lo(acc, blk(B::W3T + t), dO);
-            dHL[t] = P::masked(acc, HL[t]);
+            dHL[t] = (MI3D_MLP_BWD_TIMING_CUT & 2) ? P::cast(acc) : P::masked(acc, HL[t]);
         }
         {
             f32x16 tO = splat(0.f);
             P::mma_lo(tO, dO, blk_fresh(B::IDX));
             const KB dOp = P::cast(tO);  // lane = output index, values = the tile's samples
-            gb3 += P::sum(dOp);
+            if (!(MI3D_MLP_BWD_TIMING_CUT & 1)) gb3 += P::sum(dOp);
 #pragma unroll
             for (int t = 0; t < NTH; ++t) {
                 const KB HLp = LAYERS == 3 ? transpose(HL[t], B::IDD) : H1p[t];
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
 #pragma unroll
             for (int ti = 0; ti < NTH; ++ti) {   // dW2[i][j] += sum_s dH2[s][i] H1[s][j]
                 const KB dHLp = transpose(dHL[ti], B::IDD);
-                gb2[ti] += P::sum(dHLp);
+                if (!(MI3D_MLP_BWD_TIMING_CUT & 1)) gb2[ti] += P::sum(dHLp);
 #pragma unroll
                 for (int tj = 0; tj < NTH; ++tj) P::mma(gW2[ti][tj], dHLp, H1p[tj]);
             }
@@ -1191,7 +1197,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
                 f32x16 acc = splat(0.f);
 #pragma unroll
                 for (int tk = 0; tk < NTH; ++tk) P::mma(acc, dHL[tk], blk(B::W2T + t * NTH + tk));
-                dH1p[t] = P::masked(acc, H1p[t]);
+                dH1p[t] = (MI3D_MLP_BWD_TIMING_CUT & 2) ? P::cast(acc) : P::masked(acc, H1p[t]);
             }
         } else {
 #pragma unroll
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
             if constexpr (late_prefetch) prefetch();   // (this tile's rows are dead: the next tile's land in their registers)
 #pragma unroll
             for (int t = 0; t < NTH; ++t) {
-                gb1[t] += P::sum(dH1p[t]);
+                if (!(MI3D_MLP_BWD_TIMING_CUT & 1)) gb1[t] += P::sum(dH1p[t]);
                 P::mma(gW1[t], dH1p[t], Xp);
             }
         }

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--rows", type=int, default=13 * 10_878_976)  # the headline's evaluations per step
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--out", default="gpurun_out/mlp_ab.json")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="the two timed cases only, no equality verdict (for builds whose results are wrong on purpose: "
+                         "csrc/field.hip MI3D_MLP_BWD_TIMING_CUT)")
     a = ap.parse_args()
     from mi3d import _lib as L
     paths = a.libs.split(",") if a.libs else [a.a, a.b]
@@ -109,14 +112,16 @@ def main():
         torch.cuda.empty_cache()
 
     # every template instance of k_mlp_bwd_g (hidden 32 / 64 x 2 / 3 layers x plane type), ragged row counts, narrow inputs
-    for hid in (64, 32):
+    for hid in (() if a.timing_only else (64, 32)):
         for layers in (3, 2):
             for half_planes, half_mode in ((True, True), (False, True), (False, False)):
                 for din, rows in ((32, 1_000_003), (14, 50_001)):
                     case(rows, din, hid, layers, half_planes, half_mode, False)
     case(a.rows, 32, 64, 3, True, True, True)   # the headline: 13 points x 10.9 M samples, binary16 planes
     case(a.rows // 13, 32, 64, 3, True, True, True)   # the point-0 pass
-    res["ok"] = ok
+    if a.timing_only:
+        ok = True
+    res["ok"], res["timing_only"] = ok, a.timing_only
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
     print("MLP_AB", "OK" if ok else "MISMATCH")
