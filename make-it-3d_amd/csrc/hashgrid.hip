@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/mi3d.h"
@@ -380,6 +381,11 @@ __device__ __forceinline__ void encode_points(const PointSet &ps, const float (&
 // next unclaimed tile of every plan segment; one slot per launch in flight (zeroed in-stream before the launch)
 constexpr uint32_t kPlanSlots = 64;
 __device__ uint32_t g_encode_next[kPlanSlots * kXcds * kMaxSegs];
+// host side of the ring (mi3d_grid_encode_points_planes_counted): who used a slot last, and the event behind that launch
+struct PlanSlot { bool used = false; hipStream_t stream = nullptr; hipEvent_t done = nullptr; int device = -1; };
+PlanSlot g_slots[kPlanSlots];
+uint32_t g_slot_launches = 0;
+std::mutex g_slot_mutex;
 
 #ifdef MI3D_DEV
 // tools build only: when each XCD started, and when it finished each of its segments (100 MHz wall clock), so
@@ -1781,7 +1787,10 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                         atomicAdd(&acc[l0], fixed_point((gx * a) * scale));
                         atomicAdd(&acc[kBinEntries + l0], fixed_point((gx * bb) * scale));
                         if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
-                            const uint32_t l1 = hashed ? (l0 ^ ((1u << t) - 1u)) & (kBinEntries - 1u) : l0 + 1u;
+                            // (the flip is masked with the level's size first, as the emit and the 16-byte branch do: a
+                            // table smaller than a bin - log2_hashmap_size < 13 - must not see carry bits beyond it)
+                            const uint32_t l1 = hashed ? (l0 ^ (((1u << t) - 1u) & (T.level[lvl].size - 1u))) & (kBinEntries - 1u)
+                                                       : l0 + 1u;
                             atomicAdd(&acc[l1], fixed_point((fx * a) * scale));
                             atomicAdd(&acc[kBinEntries + l1], fixed_point((fx * bb) * scale));
                         }
@@ -1978,43 +1987,68 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     const uint32_t per_xcd = wgs_coarse;
     const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
     uint32_t *next = nullptr;
-    if (MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0) {
-        // One counter slot per launch, a ring of 64, zeroed in-stream right before the kernel.  Launches on ONE stream
-        // are ordered, so a slot coming round again is free by then.  A slot last used on ANOTHER stream may still be
-        // read by that stream's kernel (the host can run 64 launches ahead of the GPU): such a launch leaves the slot
-        // alone and deals its tiles statically (next == nullptr: the round-2 order, same planes, a few ms slower) -
-        // never two live launches on one set of counters.
-        static std::atomic<uint32_t> launches{0};
-        static void *const kUnused = reinterpret_cast<void *>(~(uintptr_t)0);
-        static std::atomic<void *> *const slot_stream = [] {
-            static std::atomic<void *> a[kPlanSlots];
-            for (auto &sref : a) sref.store(kUnused);
-            return a;
-        }();
+    // One counter slot per launch, a ring of 64, zeroed in-stream right before the kernel; a hipEvent recorded behind the
+    // kernel says when the slot is free again.  A slot coming round on the stream that used it last is free by stream
+    // order; on any other stream only once its event has completed - otherwise the launch leaves the slot alone and deals
+    // its tiles statically (next == nullptr: the round-2 order, same planes, a few ms slower at C2 size) - never two live
+    // launches on one set of counters.  (Round 4 asked the previous owner's STREAM with hipStreamQuery: a destroyed
+    // stream's handle is not a valid argument, and a launch captured into a hipGraph recorded the idle capture stream as
+    // owner while the graph later replays elsewhere - ADVICE round 4.)  A launch that is being CAPTURED always deals
+    // statically: a graph replays any number of times on any stream, it must not own a slot.
+    int slot_used = -1;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+    if (MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0 && capturing == hipStreamCaptureStatusNone) {
         uint32_t *base = nullptr;
         hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_encode_next));
         if (e != hipSuccess) return (int)e;
-        const uint32_t slot = launches.fetch_add(1u) % kPlanSlots;
-        void *const mine = reinterpret_cast<void *>(st);
-        void *const prev = slot_stream[slot].load();
-        // (a slot whose other stream has drained is free again: hipStreamQuery does not block)
-        const bool free_now = prev == kUnused || prev == mine ||
-                              hipStreamQuery(reinterpret_cast<hipStream_t>(prev)) == hipSuccess;
-        if (!free_now) (void)hipGetLastError();   // hipErrorNotReady is not a failure of this call
+        std::lock_guard<std::mutex> guard(g_slot_mutex);
+        const uint32_t slot = g_slot_launches++ % kPlanSlots;
+        PlanSlot &ps_slot = g_slots[slot];
+        bool free_now = !ps_slot.used || ps_slot.stream == st;
+        if (!free_now) {   // (hipEventQuery does not block; hipErrorNotReady is not a failure of this call)
+            free_now = hipEventQuery(ps_slot.done) == hipSuccess;
+            if (!free_now) (void)hipGetLastError();
+        }
+        int dev_now = -1;
+        (void)hipGetDevice(&dev_now);
+        if (free_now && ps_slot.done != nullptr && ps_slot.device != dev_now) {
+            // (an event belongs to the device it was created on: the ring is shared by the process's devices)
+            free_now = hipEventQuery(ps_slot.done) == hipSuccess;
+            if (free_now) { (void)hipEventDestroy(ps_slot.done); ps_slot.done = nullptr; } else (void)hipGetLastError();
+        }
+        if (free_now && ps_slot.done == nullptr) {
+            if (hipEventCreateWithFlags(&ps_slot.done, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                ps_slot.done = nullptr;
+                free_now = false;
+            }
+            ps_slot.device = dev_now;
+        }
         if (free_now) {
-            slot_stream[slot].store(mine);
+            ps_slot.used = true;
+            ps_slot.stream = st;
             next = base + (size_t)slot * kXcds * kMaxSegs;
             e = hipMemsetAsync(next, 0, sizeof(uint32_t) * kXcds * kMaxSegs, st);
             if (e != hipSuccess) return (int)e;
+            slot_used = (int)slot;
         }
     }
+    auto slot_done = [&]() {   // behind the kernel: the slot's counters are free once this event has completed
+        if (slot_used >= 0) {
+            std::lock_guard<std::mutex> guard(g_slot_mutex);
+            if (hipEventRecord(g_slots[slot_used].done, st) != hipSuccess) (void)hipGetLastError();
+        }
+    };
     if ((variant & 3) == 3)
         hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
     else if (variant & 1)
         hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
     else
         hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
-    return (int)hipGetLastError();
+    const int rc = (int)hipGetLastError();
+    slot_done();
+    return rc;
 }
 
 

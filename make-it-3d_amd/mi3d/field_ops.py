@@ -162,8 +162,22 @@ def _accumulates_into_grad(param):
                 node = param.expand_as(param).grad_fn.next_functions[0][0]
             param.__dict__["_mi3d_acc_node"] = node
         return bool(torch._C._will_engine_execute_node(node))
-    except Exception:  # noqa: BLE001 - any doubt: scatter now
+    except AttributeError as e:   # the private probe is gone from this torch build: say so once, then scatter every pass
+        _warn_once(f"torch._C._will_engine_execute_node unavailable ({e}): the point-0 deferral is off, every backward "
+                   f"pass scatters on its own (about +10 ms per C2 step)")
         return False
+    except Exception:  # noqa: BLE001 - any doubt (e.g. torch.autograd.grad: the engine refuses the question): scatter now
+        return False
+
+
+_WARNED = set()
+
+
+def _warn_once(msg):
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def _may_defer(param, P, P_active):
@@ -173,8 +187,16 @@ def _may_defer(param, P, P_active):
     does); and the engine is accumulating into `.grad` rather than returning gradients."""
     if not (grid_ops.DEFER_POINT0 and isinstance(param, grid_ops.GridParameter) and P_active == 1 and P > 1):
         return False
+    if getattr(param, "_post_accumulate_grad_hooks", None):
+        # torch DDP / FSDP (and any register_post_accumulate_grad_hook user) read the gradient from C++ right after this
+        # pass: they would miss what is parked - scatter now (grid_ops.DEFER_POINT0's note)
+        return False
     try:
         keep = torch._C._autograd._get_current_graph_task_keep_graph()
+    except AttributeError as e:
+        _warn_once(f"torch._C._autograd._get_current_graph_task_keep_graph unavailable ({e}): the point-0 deferral is "
+                   f"off, every backward pass scatters on its own (about +10 ms per C2 step)")
+        return False
     except Exception:  # noqa: BLE001
         return False
     return bool(keep) and _accumulates_into_grad(param)
@@ -188,21 +210,32 @@ def _park(param, key, item):
     if len(pend) >= 2:              # planes of forwards nobody came back to: complete them rather than pile them up
         flush_pending(param)
     item["key"] = key
-    item["event"] = torch.cuda.current_stream(item["x"].device).record_event()
+    item["stream"] = torch.cuda.current_stream(item["x"].device)
+    item["event"] = item["stream"].record_event()
     pend.append(item)
 
 
-def _take_parked(param, key):
-    """The planes an earlier pass through the forward `key` parked on `param` (None if none), removed from the list."""
+def _find_parked(param, key):
+    """The item an earlier pass through the forward `key` parked on `param` (None if none).  It STAYS parked until the
+    scatter that takes its planes along has been issued (`_consume_parked`): if that scatter raises - a dtype / shape
+    check, an out-of-memory - the first pass's gradient is still there for the next reader of `.grad`."""
     pend = None if param is None else param.__dict__.get("_mi3d_pending")
-    if not pend:
-        return None
-    for i, it in enumerate(pend):
+    for it in pend or ():
         if it["key"] == key:
-            del pend[i]
-            torch.cuda.current_stream(it["x"].device).wait_event(it["event"])
-            return it["dplanes"]
+            cur = torch.cuda.current_stream(it["x"].device)
+            cur.wait_event(it["event"])
+            if it.get("stream") is not None and it["stream"] != cur:
+                # parked on another stream: the caching allocator must not hand the block back to that stream's
+                # allocations while this one still reads it
+                it["dplanes"].record_stream(cur)
+            return it
     return None
+
+
+def _consume_parked(param, item):
+    pend = None if param is None else param.__dict__.get("_mi3d_pending")
+    if pend and item is not None:
+        pend[:] = [it for it in pend if it is not item]
 
 
 @torch.no_grad()
@@ -212,13 +245,16 @@ def flush_pending(param, key=None):
     if not pend:
         return
     items = [it for it in pend if key is None or it["key"] == key]
-    pend[:] = [it for it in pend if not (key is None or it["key"] == key)]
     for it in items:
         x = it["x"]
         with L.on(x):
-            torch.cuda.current_stream(x.device).wait_event(it["event"])
+            cur = torch.cuda.current_stream(x.device)
+            cur.wait_event(it["event"])
+            if it.get("stream") is not None and it["stream"] != cur:
+                it["dplanes"].record_stream(cur)
             g = _scatter_planes(it["dplanes"], x, None, it["offs"], it["P0"], it["bound"], it["cfg"], it["step"],
                                 it["n_params"], 1)
+        pend[:] = [other for other in pend if other is not it]   # only once its scatter has been issued
         real = torch.Tensor.grad.__get__(param)
         if real is None:
             torch.Tensor.grad.__set__(param, g.view_as(param))
@@ -408,9 +444,10 @@ class _Field(Function):
                                                    step=step, n_params=n_params))
                 gp = None
             else:
-                extra0 = _take_parked(param, ctx.forward_key) if P_active > 1 else None
+                parked = _find_parked(param, ctx.forward_key) if P_active > 1 else None
                 gp = _scatter_planes(dplanes, x, x2 if has_x2 else None, offs, P0, bound, cfg, step, n_params, P_active,
-                                     extra0=extra0)
+                                     extra0=None if parked is None else parked["dplanes"])
+                _consume_parked(param, parked)   # (after the call: a scatter that raised leaves the planes parked)
         return (gp, *wg, *none[:11])
 
 

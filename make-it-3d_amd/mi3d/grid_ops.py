@@ -72,7 +72,17 @@ def _timed(kind, launch, evals):
 # is still parked when somebody READS `encoder.params.grad` is scattered then (GridParameter.grad), so every reader -
 # GradScaler.unscale_, clip_grad_norm_, the optimizer, an all-reduce bucket - sees the complete gradient, second backward
 # or not.  Set to False to scatter every pass immediately (round 3's behaviour).
+#
+# NOT supported together with readers that bypass Python: torch's DDP reducer, FSDP and post-accumulate-grad hooks read
+# the gradient through the C++ accessor and would see it without the parked part whenever no second pass consumes it.
+# field_ops._may_defer therefore turns the deferral off for a parameter that carries post-accumulate-grad hooks (what
+# DDP / FSDP register); mi3d.dp's flat bucket reads `.grad` from Python and composes with it.
 DEFER_POINT0 = True
+
+
+def _rebuild_grid_parameter(data, requires_grad):
+    """pickle / torch.save / mp.spawn: a GridParameter comes back as a GridParameter (module-level, so it pickles)."""
+    return GridParameter(data, requires_grad)
 
 
 class GridParameter(torch.nn.Parameter):
@@ -85,6 +95,17 @@ class GridParameter(torch.nn.Parameter):
         if data is None:
             data = torch.empty(0)
         return torch.Tensor._make_subclass(cls, data, requires_grad)
+
+    def __reduce_ex__(self, proto):
+        """The per-process state this class keeps in its __dict__ - parked gradient planes with their HIP events
+        (`_mi3d_pending`), the cached AccumulateGrad node (`_mi3d_acc_node`) - is not serialisable and means nothing in
+        another process: whatever is parked is scattered first (the pickled gradient state is complete), and only
+        (data, requires_grad) travel, re-built as a GridParameter (nn.Parameter's own __reduce_ex__ would pickle the
+        __dict__ and fail on the events after the first deferred backward pass - ADVICE round 4)."""
+        if self.__dict__.get("_mi3d_pending"):
+            from . import field_ops
+            field_ops.flush_pending(self)
+        return _rebuild_grid_parameter, (self.data, self.requires_grad)
 
     @property
     def grad(self):

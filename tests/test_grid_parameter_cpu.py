@@ -48,3 +48,46 @@ def test_grid_parameter_is_a_parameter_with_a_completing_grad(monkeypatch):
     assert isinstance(enc64.params, grid_ops.GridParameter) and enc64.params.dtype == torch.float64
     enc.load_state_dict(enc.state_dict())
     assert isinstance(enc.params, grid_ops.GridParameter)
+
+
+def test_grid_parameter_pickles_without_its_per_process_state(monkeypatch):
+    """torch.save(model) / mp.spawn / copy.copy after a deferred backward pass: the parked planes (HIP events) and the
+    cached AccumulateGrad node in the parameter's __dict__ must not reach the pickle - what is parked is completed first,
+    and the parameter comes back as a GridParameter."""
+    import io
+    import pickle
+    import threading
+    from mi3d import field_ops, grid_ops
+    p = grid_ops.GridParameter(torch.arange(6, dtype=torch.float32))
+    (p * 3).sum().backward()
+    flushed = []
+
+    def fake_flush(param, key=None):
+        flushed.append(len(param.__dict__["_mi3d_pending"]))
+        param.__dict__["_mi3d_pending"].clear()
+    monkeypatch.setattr(field_ops, "flush_pending", fake_flush)
+    p.__dict__["_mi3d_pending"] = [{"key": object(), "event": threading.Lock()}]   # (a lock does not pickle either)
+    p.__dict__["_mi3d_acc_node"] = threading.Lock()
+    q = pickle.loads(pickle.dumps(p))
+    assert flushed == [1] and isinstance(q, grid_ops.GridParameter) and q.requires_grad and torch.equal(q, p)
+    assert "_mi3d_pending" not in q.__dict__ and "_mi3d_acc_node" not in q.__dict__
+    buf = io.BytesIO()
+    mod = torch.nn.Module()
+    mod.params = p
+    torch.save(mod, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert isinstance(back.params, grid_ops.GridParameter) and torch.equal(back.params, p)
+    # the state_dict route stores plain tensors, as ever
+    sd = pickle.loads(pickle.dumps(mod.state_dict()))
+    assert torch.equal(sd["params"], p.detach())
+
+
+def test_deferral_is_off_for_parameters_with_post_accumulate_grad_hooks():
+    """torch DDP / FSDP read the gradient from C++ right after a backward pass (post-accumulate-grad hooks): a pass whose
+    planes were parked would be missing there, so such a parameter is never deferred."""
+    from mi3d import field_ops, grid_ops
+    p = grid_ops.GridParameter(torch.zeros(4))
+    assert grid_ops.DEFER_POINT0
+    p.register_post_accumulate_grad_hook(lambda t: None)
+    assert field_ops._may_defer(p, 13, 1) is False

@@ -382,3 +382,37 @@ def test_plane_kernels_are_bit_identical_to_the_row_kernel(cuda, oracle, bound, 
         got = planes.permute(1, 0, 2).reshape(P * n, 2 * levels)
         want = rows.half() if half else rows
         assert torch.equal(got, want), (half, float((got.float() - want.float()).abs().max()))
+
+
+@pytest.mark.parametrize("log2", [10, 12])
+@pytest.mark.parametrize("half", [False, True])
+def test_binned_scatter_with_hash_tables_smaller_than_a_bin(cuda, oracle, half, log2):
+    """log2_hashmap_size below 13: a hashed level is smaller than one reduce bin (8192 entries), so the x + 1 partner of a
+    pair record - e1 = e0 ^ (2^t - 1), t = 1 + trailing ones of cx - must be masked with the LEVEL's size, not the bin's:
+    with res 2048 and cx ending in ten or more ones the unmasked flip lands past the table (the 12-byte
+    branch of k_bin_reduce masked with the bin only).  Both record types against the oracle."""
+    from mi3d import field_ops, grid_ops
+    rng = np.random.default_rng(29)
+    cfg = oracle.GridConfig(log2_hashmap_size=log2)
+    kcfg = dict(n_levels=cfg.n_levels, base_resolution=cfg.base_resolution, per_level_scale=cfg.per_level_scale,
+                log2_hashmap_size=log2)
+    n = 4000
+    x = _ray_like_points(rng, n, 1.0)
+    # cells whose x index ends in many ones on the finest levels (res 2048: cx = 1023, 511, 2047 - the last clamps)
+    for i, cx in enumerate((1023, 511, 1535, 255, 767)):
+        x[200 * i:200 * i + 100, 0] = np.float32((cx + 0.3) / 2048.0 * 2.0 - 1.0)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=False)
+    P = offs.shape[0]
+    dt = np.float16 if half else np.float32
+    dout = rng.normal(size=(n, P, 16, 2)).astype(dt)
+    planes = np.ascontiguousarray(dout.transpose(2, 1, 0, 3).reshape(16, P * n, 2))
+    with record_scatter_workspaces() as arenas:
+        g = field_ops.scatter_binned(T(x, cuda), None, offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params).cpu().numpy()
+    assert len(arenas) == 1 and arenas[0] > 0
+    ref = np.zeros(cfg.n_params, np.float64)
+    for p, pts in enumerate(_points(x, x, offs, P0, 1.0)):
+        h01 = ((pts + np.float32(1.0)) / np.float32(2.0)).astype(np.float32)
+        ref += oracle.hashgrid_backward(h01, dout[:, p].astype(np.float32).reshape(n, 32), cfg)
+    for l in range(16):   # per level: a misplaced partner shows on its own level, whatever the others' magnitudes are
+        a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
+        assert np.abs(g[a:b] - ref[a:b]).max() <= 5e-5 * np.abs(ref[a:b]).max() + 1e-6, l
