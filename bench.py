@@ -335,6 +335,50 @@ def rank_views(rank, views):
     return [rank * views + v for v in range(views)], 1234 + rank
 
 
+def gather_rank_records(rec):
+    """Every rank's record on every rank (torch.distributed.all_gather_object: works on gloo and on NCCL = RCCL); a list of
+    one without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [rec]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, rec)
+    return out
+
+
+def summarise_ranks(records, expected_updates, backend, group_world_size, launcher_world_size):
+    """What a line measured at N > 1 must say about ITSELF, since nobody else was there: the
+    world size the process group really had next to the launcher's, the backend, every rank's own step time (its clock
+    from the first timed step to its own device synchronisation, BEFORE the closing barrier), the time its stream spent
+    inside the gradient all-reduce (HIP events around the collective: a fast rank waits there for the slowest one), loss
+    scale, applied optimizer updates and peak memory per rank - and `valid`: false with a reason when the ranks disagree
+    on what they did (an update applied on one rank and skipped on another cannot happen with a summed gradient bucket;
+    a different scale or step count means the ranks did not run the same job)."""
+    import statistics
+    recs = sorted(records, key=lambda r: r["rank"])
+    ms = [r["ms_per_step_local"] for r in recs]
+    ar = [r["all_reduce_ms_per_step"] for r in recs]
+    problems = []
+    if group_world_size != launcher_world_size:
+        problems.append(f"process group has {group_world_size} ranks, the launcher announced {launcher_world_size}")
+    if [r["rank"] for r in recs] != list(range(group_world_size)):
+        problems.append(f"records from ranks {[r['rank'] for r in recs]}, expected 0..{group_world_size - 1}")
+    for key, what in (("optimizer_steps_applied", "applied optimizer updates"), ("grad_scaler_scale", "loss scale before"),
+                      ("grad_scaler_scale_after", "loss scale after"), ("steps", "timed steps")):
+        vals = [r[key] for r in recs]
+        if len(set(vals)) > 1:
+            problems.append(f"ranks disagree on {what}: {vals}")
+    if recs and recs[0]["optimizer_steps_applied"] != expected_updates:
+        problems.append(f"{expected_updates - recs[0]['optimizer_steps_applied']} timed step(s) skipped the optimizer update")
+    return {"backend": backend, "rccl_world_size": group_world_size, "launcher_world_size": launcher_world_size,
+            "per_rank": recs,
+            "ms_per_step_local": {"min": min(ms), "median": statistics.median(ms), "max": max(ms)},
+            "all_reduce_ms_per_step": {"min": min(ar), "median": statistics.median(ar), "max": max(ar)},
+            "compute_ms_per_step": {"min": min(m - a for m, a in zip(ms, ar)), "max": max(m - a for m, a in zip(ms, ar))},
+            "peak_mem_GiB": [r["peak_mem_GiB"] for r in recs],
+            "valid": not problems, "problems": problems}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: become the launcher (one rank per GPU on this node)."""
     port = 29500 + (os.getpid() % 2000)
@@ -466,7 +510,8 @@ def main():
                 clock["i"] += 1
                 # (the step's own optimizer.zero_grad clears the gradients, which ARE the flat bucket's views)
                 sds_step.sds_train_step(the_model, guidance, text_z, the_optimizer, the_scaler, ro, rd, ds, wl["H"],
-                                        wl["W"], opt, sds_backward=schedule, t=t_fixed, grad_sync=sync)
+                                        wl["W"], opt, sds_backward=schedule, t=step_extra.get("t", t_fixed), grad_sync=sync,
+                                        **{k: v for k, v in step_extra.items() if k != "t"})
         step.clock = clock
         return step
 
@@ -481,9 +526,13 @@ def main():
         return wrapper
     guidance._predict_noise = timed("sd_guidance", _sds)
     optimizer.step = timed("optimizer", _opt_step)
+    # the gradient all-reduce between HIP events on the launch stream (a rank that finished its backward early WAITS in this
+    # collective for the slowest rank: its per-rank spread is the skew the step time hides)
+    grad_sync = timed("all_reduce", bucket.all_reduce_mean) if dist.is_initialized() else bucket.all_reduce_mean
+    step_extra = {}     # extra arguments of sds_train_step (the denoise + CLIP variant sets them)
 
     def run(records, schedule, steps, warmup):
-        step = make_step(model, optimizer, scaler, schedule, bucket.all_reduce_mean)
+        step = make_step(model, optimizer, scaler, schedule, grad_sync)
         if not render_only:
             step.clock["i"] = 1   # warm-up steps do not refresh the grid ...
         for _ in range(warmup):
@@ -504,6 +553,7 @@ def main():
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        local = time.perf_counter() - t0      # this rank's own clock, before it waits for the others
         if args.profile_run:
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
@@ -518,12 +568,14 @@ def main():
         info = {"applied": len(prof.get("optimizer", [])), "scale_before": scale0,
                 "scale_after": scaler.get_scale() if not render_only else None,
                 "refreshes": 0 if render_only else step.clock["refreshes"],
-                "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+                "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                "local_ms_per_step": 1e3 * local / steps,
+                "all_reduce_ms_per_step": sum(a.elapsed_time(b) for a, b in prof.get("all_reduce", [])) / steps}
         return elapsed, prof, info
 
     log(f"{args.workload}: timing {args.steps} steps of the headline variant {HEADLINE} on {world} GPU(s)")
     # settle the loss scale (untimed; before the W warm-up steps of the contract)
-    settle = make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)
+    settle = make_step(model, optimizer, scaler, HEADLINE[1], grad_sync)
     good, tries = 0, 0
     while not render_only and opt.fp16 and good < 4 and tries < 60:
         before = scaler.get_scale()
@@ -541,7 +593,7 @@ def main():
     census = None
     if not render_only:
         grid_ops.CENSUS = []
-        make_step(model, optimizer, scaler, HEADLINE[1], bucket.all_reduce_mean)()
+        make_step(model, optimizer, scaler, HEADLINE[1], grad_sync)()
         torch.cuda.synchronize()
         raw, grid_ops.CENSUS = grid_ops.CENSUS, None
         census = {}
@@ -574,14 +626,67 @@ def main():
         elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
         log(f"headline (re-timed): {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of "
             f"{args.steps * views} updates applied, loss scale {info['scale_before']} -> {info['scale_after']}")
+    ranks = None
+    if dist.is_initialized() and not render_only:
+        ranks = summarise_ranks(
+            gather_rank_records({"rank": rank, "steps": args.steps, "ms_per_step_local": info["local_ms_per_step"],
+                                 "all_reduce_ms_per_step": info["all_reduce_ms_per_step"],
+                                 "optimizer_steps_applied": info["applied"], "grad_scaler_scale": info["scale_before"],
+                                 "grad_scaler_scale_after": info["scale_after"], "peak_mem_GiB": info["peak_mem_GiB"],
+                                 "views": view_ids, "device": torch.cuda.get_device_name(dev)}),
+            args.steps * views, dist.get_backend(), dist.get_world_size(), world)
     steps_run_total = tries + 1 + (1 + retimed) * (args.warmup + args.steps)   # settle + census + warm-up + timed
     variants = {f"records={HEADLINE[0]},sds_backward={HEADLINE[1]}": 1e3 * elapsed / args.steps}
-    dense_step = None
+    dense_step, clip_step = None, None
     if args.variant_steps > 0 and not render_only:
         e, _, _ = run("fp32", "single", args.variant_steps, 1)
         variants["records=fp32,sds_backward=single"] = 1e3 * e / args.variant_steps
         e, _, _ = run("fp32", "overlapped", args.variant_steps, 1)
         variants["records=fp32,sds_backward=overlapped"] = 1e3 * e / args.variant_steps
+        # ---- the guidance's OTHER branch (nerf/sd.py:153-159): for t/1000 <= 0.4 - t ~ U{200..600}: 201 of 401 draws - a
+        # novel-view step injects NO SDS gradient; it takes one DDIM step, decodes the latents (VAE decoder, no_grad), runs
+        # two CLIP image towers + one text tower on the denoised image and adds 10 x those similarities - constants w.r.t.
+        # the NeRF - to the regularisers.  Timed here at t = 300 with full-size stand-ins (VAE decoder ~49 M
+        # parameters, ViT-B/16 + text tower ~150 M); the NeRF side is then ONE backward pass (the 13-point regulariser
+        # pass, nothing parked), the VAE encoder still runs forward (its latents are noised and denoised) but never backward.
+        if True:
+            try:
+                ref_rgb = torch.rand(1, 3, 512, 512, device=dev)
+                if guidance.vae_decoder is None:
+                    with torch.random.fork_rng(devices=[dev]):
+                        torch.manual_seed(7)
+                        guidance.vae_decoder = sd_standin.VAEDecoderSD().to(dev)
+                    for prm in guidance.vae_decoder.parameters():
+                        prm.requires_grad_(False)
+                with torch.random.fork_rng(devices=[dev]):
+                    torch.manual_seed(8)
+                    clip_model = sd_standin.CLIPStandIn().to(dev).half()
+                for frozen, label in ((True, "t300_clip_branch"), (False, "t300_clip_branch_clip_weights_unfrozen")):
+                    # (the reference freezes the guidance's parameters only, nerf/utils.py:280-281: its CLIP model keeps
+                    # requires_grad and scaler.scale(loss).backward() walks back into the CLIP towers for nothing - the
+                    # second figure; the first is the same step with CLIP frozen)
+                    for prm in clip_model.parameters():
+                        prm.requires_grad_(not frozen)
+                    step_extra.update(t=300, clip_model=clip_model, ref_rgb=ref_rgb, ref_text="a toy")
+                    try:
+                        e, cprof, cinfo = run("fp32", "reference", args.variant_steps, 1)
+                    finally:
+                        step_extra.clear()
+                        clip_model.zero_grad(set_to_none=True)
+                    variants[label] = 1e3 * e / args.variant_steps
+                    if frozen:
+                        clip_step = {"ms_per_step": variants[label], "t": 300,
+                                     "optimizer_steps_applied": cinfo["applied"],
+                                     "optimizer_steps_attempted": args.variant_steps * views,
+                                     "scatter_ms_per_step": sum(a.elapsed_time(b) for a, b in cprof.get("scatter", [])) / args.variant_steps,
+                                     "phases_ms_per_step": {k[6:]: sum(a.elapsed_time(b) for a, b in v) / args.variant_steps
+                                                            for k, v in cprof.items() if k.startswith("phase:")}}
+                del clip_model
+                guidance.vae_decoder = None
+                torch.cuda.empty_cache()
+            except Exception as ex:  # noqa: BLE001 - an extra: it must not take the line down
+                log(f"denoise + CLIP branch variant failed: {ex!r}")
+                step_extra.clear()
         # the headline schedule with the scatter's zero-skip DEFEATED: every gradient pair that binary16 underflowed to
         # an exact zero is replaced by +-2^-24 (the smallest binary16 subnormal) before the scatter, so the emit and the
         # reduce process all 141 M x 16 pairs.  The replacement is one extra pass over the gradient planes, timed on its
@@ -711,7 +816,25 @@ def main():
             line["scatter_dense_gradients"] = dense
         if dense_step is not None:
             line["dense_gradient_step"] = dense_step
-        if not render_only and opt.fp16:
+        if clip_step is not None:
+            # on novel views past diff_iters the guidance draws t ~ U{200..600}; t <= 400 (201 of 401 draws)
+            # takes the denoise + CLIP branch.  The blend is what an average such step costs; `value` stays the SDS branch
+            # (t = 500), which is the configuration BASELINE.json's metric names.
+            p_clip = 201.0 / 401.0
+            blend = p_clip * clip_step["ms_per_step"] + (1 - p_clip) * line["ms_per_step"]
+            line["guidance_branches"] = {
+                "sds_branch_t500_ms_per_step": line["ms_per_step"], "denoise_clip_branch_t300": clip_step,
+                "share_of_novel_view_steps_on_the_clip_branch": p_clip,
+                "blended_ms_per_step": blend, "blended_view_steps_per_s": world * views * 1e3 / blend,
+                "note": "nerf/sd.py:153-159: t/1000 <= 0.4 takes one DDIM step + VAE decode + 2 CLIP image + 1 text "
+                        "forward on the denoised image and injects no SDS gradient (the NeRF sees the regulariser pass "
+                        "only); full-size random-weight stand-ins (mi3d/sd_standin.py)"}
+        if ranks is not None:
+            line["ranks"] = ranks
+            if not ranks["valid"]:
+                line["valid"] = False
+                line["invalid_reason"] = "; ".join(ranks["problems"])
+        if not render_only and opt.fp16 and line.get("valid", True):
             line["valid"] = info["applied"] == args.steps * views
             if not line["valid"]:
                 line["invalid_reason"] = (f"{args.steps * views - info['applied']} timed step(s) skipped the optimizer "

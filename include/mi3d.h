@@ -32,7 +32,7 @@ extern "C" {
 #define MI3D_MAX_LEVELS 16
 #define MI3D_MAX_POINTS 16
 
-/* the ABI version: 3 (2 + mi3d_grid_scatter_binned_plus; every version-2 entry point is unchanged) */
+/* the ABI version: 4 (3 + the compact-round inference loop of Part 1b; every version-3 entry point is unchanged) */
 int mi3d_abi_version(void);
 const char *mi3d_last_error_string(int err);
 
@@ -123,6 +123,35 @@ int mi3d_composite_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_th
                             void *stream);
 int mi3d_compact_alive_ctl(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
                            uint32_t align, uint32_t max_steps, void *stream);
+
+/* The same loop with the samples of a round COMPACTED and the round size set by a row BUDGET (round 5).  The reference's
+ * round takes n_step = clamp(N / n_alive, 1, 8) steps of every alive ray and lays them out at n * n_step, so a 128 x 128
+ * render is ~280 rounds of at most 16 384 rows - latency, not work.  A ray's result does not depend on how its samples
+ * are cut into rounds (it carries t in rays_t and its transmittance in weights_sum), so here a round takes
+ * n_step = clamp(budget / n_alive, step_min, step_max) steps and the march packs what the rays actually emitted into one
+ * slab per ray (wave scan + one atomic per wave on ctl[2], as the training march does): a render is a handful of rounds
+ * and no row of a finished ray is evaluated.  ctl (int32[8]): [0] n_alive, [1] n_step, [2] rows of this round (written by
+ * the march, zeroed by begin / compact), [3] steps done, [4] rounds done, [5] budget, [6] step_min, [7] step_max.
+ *   mi3d_infer_begin2            rays_alive[i] = i, ctl for round 0
+ *   mi3d_march_rays_compact_ctl  ray_slab int32[n_alive_max][2] = (first row, rows) per alive slot; t_next f32[n_alive_max] =
+ *                                the march's own t behind its last step (what the next round resumes from: the restart is
+ *                                exact, so the sample sequence of a ray is the same for every budget); a ray whose slab
+ *                                would pass rows_cap emits nothing (cannot happen when rows_cap >= max(budget, N step_min))
+ *   mi3d_composite_rays_compact_ctl  composite_rays over each ray's slab; a ray that used all n_step rows resumes at t_next
+ *   mi3d_compact_alive_ctl2      the compaction + the next round's plan                                       */
+int mi3d_infer_begin2(int32_t *ctl, int32_t *rays_alive, uint32_t N, uint32_t budget_rows, uint32_t step_min,
+                      uint32_t step_max, void *stream);
+int mi3d_march_rays_compact_ctl(int32_t *ctl, uint32_t n_alive_max, const int32_t *rays_alive, const float *rays_t,
+                                const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, uint32_t rows_cap,
+                                float *xyzs, float *dirs, float *deltas, int32_t *ray_slab, float *t_next,
+                                const float *noises, void *stream);
+int mi3d_composite_rays_compact_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_thresh, int32_t *rays_alive,
+                                    float *rays_t, const int32_t *ray_slab, const float *t_next, const float *sigmas,
+                                    const float *rgbs, const float *normals, const float *deltas, float *weights_sum,
+                                    float *depth, float *image, float *normal, void *stream);
+int mi3d_compact_alive_ctl2(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
+                            uint32_t max_steps, void *stream);
 
 /* ------------------------------------------------------------------ Part 2: hash-grid encoding */
 

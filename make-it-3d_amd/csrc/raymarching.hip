@@ -564,6 +564,8 @@ __global__ void k_composite_infer_ctl(const int32_t *__restrict__ ctl, float T_t
 // Order-preserving compaction of the rays still alive (entries >= 0) - what the boolean mask does - by ONE 1024-thread
 // workgroup (N is a few 10^4): wave64 ballot ranks inside a wave, an LDS scan over the 16 waves, a running base across
 // chunks.  The same kernel advances the loop state and plans the next round.
+__device__ __forceinline__ void infer_plan2(int32_t n_alive, int32_t *ctl);   // (the budget plan, defined further down)
+template <bool BUDGET>
 __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict__ ctl, const int32_t *__restrict__ in,
                                                             int32_t *__restrict__ out, uint32_t N, uint32_t align,
                                                             uint32_t max_steps) {
@@ -598,10 +600,148 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
         const int32_t done = ctl[CTL_DONE] + ctl[CTL_STEP];
         int32_t alive = (int32_t)base_s;
         if (done >= (int32_t)max_steps) alive = 0;  // `while step < max_steps` of the reference loop
-        infer_plan(alive, N, align, ctl);
+        if (BUDGET) infer_plan2(alive, ctl); else infer_plan(alive, N, align, ctl);
         ctl[CTL_DONE] = done;
         ctl[CTL_ROUNDS] += 1;
     }
+}
+
+// ---------------------------------------------------------------- the same loop, compact rounds under a row budget
+// (round 5; include/mi3d.h Part 1b, second half).  What the reference's round structure costs: n_step = clamp(N /
+// n_alive, 1, 8) steps per alive ray, laid out at n * n_step, so a round never holds more than N rows - a 128 x 128 render
+// is ~280 rounds x (march, gather, MLP, head, composite, compaction) of a few thousand rows each: launch latency, two
+// orders of magnitude below what the training forward pushes through the same kernels per millisecond.  A ray's result
+// does not depend on where its samples are cut into rounds: its t travels in rays_t, its transmittance in weights_sum
+// (T = 1 - weights_sum at every step, raymarching.cu:1075), and every accumulator is read and written back exactly.  So a
+// round here takes n_step = clamp(budget / n_alive, step_min, step_max) steps, and the march PACKS what the rays really
+// emitted - count pass, wave64 scan, one atomic per wave on the round's row counter, write pass: the training march's
+// scheme - so rays that miss, finish or terminate cost no rows.  The restart point of a ray is the march's own t (t_next),
+// not the composite's running sum of the float differences deltas[.,1] (equal whenever those sums are exact, i.e. almost
+// always): a ray's sample sequence is then EXACTLY the uninterrupted march's, whatever the budget - two budgets give
+// bit-identical images (tests/test_raymarching_gpu.py).
+enum : int { CTL_BUDGET = 5, CTL_STEP_MIN = 6, CTL_STEP_MAX = 7 };
+
+__device__ __forceinline__ void infer_plan2(int32_t n_alive, int32_t *ctl) {
+    int32_t n_step = 0;
+    if (n_alive > 0) {
+        n_step = ctl[CTL_BUDGET] / n_alive;
+        n_step = n_step > ctl[CTL_STEP_MAX] ? ctl[CTL_STEP_MAX] : n_step;
+        n_step = n_step < ctl[CTL_STEP_MIN] ? ctl[CTL_STEP_MIN] : n_step;
+    }
+    ctl[CTL_ALIVE] = n_alive; ctl[CTL_STEP] = n_step; ctl[CTL_ROWS] = 0;
+}
+
+__global__ void k_infer_begin2(int32_t *__restrict__ ctl, int32_t *__restrict__ rays_alive, uint32_t N, uint32_t budget,
+                               uint32_t step_min, uint32_t step_max) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) rays_alive[i] = (int32_t)i;
+    if (i == 0) {
+        ctl[CTL_BUDGET] = (int32_t)budget; ctl[CTL_STEP_MIN] = (int32_t)step_min; ctl[CTL_STEP_MAX] = (int32_t)step_max;
+        infer_plan2((int32_t)N, ctl);
+        ctl[CTL_DONE] = 0; ctl[CTL_ROUNDS] = 0;
+    }
+}
+
+// lane = alive slot.  Whole waves stay in the kernel (the scan needs every lane); a lane beyond n_alive counts zero.
+__global__ __launch_bounds__(128) void k_march_infer_compact_ctl(
+    int32_t *__restrict__ ctl, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+    uint32_t C, uint32_t H, const uint8_t *__restrict__ bits, const float *__restrict__ fars, uint32_t rows_cap,
+    float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ ray_slab,
+    float *__restrict__ t_next, const float *__restrict__ noises) {
+    const uint32_t n_alive = (uint32_t)ctl[CTL_ALIVE], n_step = (uint32_t)ctl[CTL_STEP];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n_alive) return;   // (block-uniform)
+    const int lane = lane_id();
+    const bool live = n < n_alive;
+    MarchGrid g;
+    march_grid_init(g, bits, bound, dt_gamma, max_steps, C, H);
+    MarchRay r;
+    int32_t index = 0;
+    float far = 0.f, t0 = 0.f;
+    if (live) {
+        index = rays_alive[n];
+        march_ray_init(r, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3);
+        far = fars[index];
+        // the jitter applies to the first round only (renderer.py:546: `perturb if step == 0 else False`)
+        const float noise = (noises != nullptr && ctl[CTL_ROUNDS] == 0) ? noises[n] : 0.f;
+        t0 = march_t0(rays_t[index], noise, g);
+    }
+    // pass 1: how many occupied steps (at most n_step) does the ray take this round, and where does its march stand then
+    uint32_t count = 0;
+    float t = t0;
+    if (live) {
+        float x, y, z, dt;
+        while (t < far && count < n_step)
+            if (march_step(r, g, t, x, y, z, dt)) ++count;
+    }
+    const uint32_t incl = wave_scan_add_u32(count, lane);
+    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+    uint32_t base = 0;
+    if (lane == 0 && wave_total != 0u) base = (uint32_t)atomicAdd(ctl + CTL_ROWS, (int)wave_total);
+    base = __shfl(base, 0, kWave);
+    uint32_t offset = base + incl - count;
+    if (offset + count > rows_cap) count = 0;   // (cannot happen with rows_cap >= max(budget, N step_min): dropped, not an error)
+    if (!live) return;
+    ray_slab[(size_t)n * 2] = (int32_t)offset;
+    ray_slab[(size_t)n * 2 + 1] = (int32_t)count;
+    t_next[n] = t;
+    // pass 2: the same walk, written
+    float *px = xyzs + (size_t)offset * 3, *pd = dirs + (size_t)offset * 3, *pl = deltas + (size_t)offset * 2;
+    t = t0;
+    float last_t = t0, x, y, z, dt;
+    uint32_t step = 0;
+    while (t < far && step < count) {
+        if (march_step(r, g, t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            ++step;
+        }
+    }
+}
+
+// composite_rays (raymarching.cu:1039-1114) over the ray's slab: same arithmetic, same break rule; the "rows past the
+// ray's end are zero" sentinel of the n * n_step layout is the slab's row count here
+__global__ void k_composite_infer_compact_ctl(const int32_t *__restrict__ ctl, float T_thresh,
+                                              int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                                              const int32_t *__restrict__ ray_slab, const float *__restrict__ t_next,
+                                              const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                              const float *__restrict__ normals, const float *__restrict__ deltas,
+                                              float *__restrict__ weights_sum, float *__restrict__ depth,
+                                              float *__restrict__ image, float *__restrict__ normal) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (uint32_t)ctl[CTL_ALIVE]) return;
+    const uint32_t n_step = (uint32_t)ctl[CTL_STEP];
+    const int32_t index = rays_alive[n];
+    const uint32_t offset = (uint32_t)ray_slab[(size_t)n * 2], count = (uint32_t)ray_slab[(size_t)n * 2 + 1];
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2,
+                *nm = normals + (size_t)offset * 3;
+    float t = rays_t[index], d = depth[index], ws = weights_sum[index];
+    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+    float nx = normal[(size_t)index * 3], ny = normal[(size_t)index * 3 + 1], nz = normal[(size_t)index * 3 + 2];
+    uint32_t step = 0;
+    while (step < count) {
+        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+        const float T = 1.0f - ws;  // transmittance carried across rounds through weights_sum
+        const float w = alpha * T;
+        ws += w;
+        t += dl[1];
+        d += w * t;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        nx += w * nm[0]; ny += w * nm[1]; nz += w * nm[2];
+        if (T < T_thresh) break;
+        ++s; c += 3; dl += 2; nm += 3;
+        ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t_next[n];
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    normal[(size_t)index * 3] = nx; normal[(size_t)index * 3 + 1] = ny; normal[(size_t)index * 3 + 2] = nz;
 }
 
 }  // namespace
@@ -610,7 +750,7 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 3; }
+int mi3d_abi_version(void) { return 4; }
 const char *mi3d_last_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
 int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
@@ -762,8 +902,49 @@ int mi3d_composite_rays_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_th
 int mi3d_compact_alive_ctl(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
                            uint32_t align, uint32_t max_steps, void *stream) {
     if (N == 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_compact_alive_ctl, dim3(1), dim3(1024), 0, as_stream(stream), ctl, rays_alive_in, rays_alive_out,
-                       N, align, max_steps);
+    hipLaunchKernelGGL(k_compact_alive_ctl<false>, dim3(1), dim3(1024), 0, as_stream(stream), ctl, rays_alive_in,
+                       rays_alive_out, N, align, max_steps);
+    return launch_status();
+}
+
+/* ---- the same loop in compact rounds under a row budget (k_infer_begin2 .. k_composite_infer_compact_ctl above) */
+int mi3d_infer_begin2(int32_t *ctl, int32_t *rays_alive, uint32_t N, uint32_t budget_rows, uint32_t step_min,
+                      uint32_t step_max, void *stream) {
+    if (N == 0 || budget_rows == 0 || step_min == 0 || step_max < step_min || N > 0x7FFFFFFFu || budget_rows > 0x7FFFFFFFu)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_infer_begin2, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), ctl, rays_alive, N, budget_rows,
+                       step_min, step_max);
+    return launch_status();
+}
+
+int mi3d_march_rays_compact_ctl(int32_t *ctl, uint32_t n_alive_max, const int32_t *rays_alive, const float *rays_t,
+                                const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, uint32_t rows_cap,
+                                float *xyzs, float *dirs, float *deltas, int32_t *ray_slab, float *t_next,
+                                const float *noises, void *stream) {
+    if (n_alive_max == 0) return 0;
+    hipLaunchKernelGGL(k_march_infer_compact_ctl, dim3(cdiv(n_alive_max, 128)), dim3(128), 0, as_stream(stream), ctl,
+                       rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, rows_cap, xyzs, dirs,
+                       deltas, ray_slab, t_next, noises);
+    return launch_status();
+}
+
+int mi3d_composite_rays_compact_ctl(const int32_t *ctl, uint32_t n_alive_max, float T_thresh, int32_t *rays_alive,
+                                    float *rays_t, const int32_t *ray_slab, const float *t_next, const float *sigmas,
+                                    const float *rgbs, const float *normals, const float *deltas, float *weights_sum,
+                                    float *depth, float *image, float *normal, void *stream) {
+    if (n_alive_max == 0) return 0;
+    hipLaunchKernelGGL(k_composite_infer_compact_ctl, dim3(cdiv(n_alive_max, 128)), dim3(128), 0, as_stream(stream), ctl,
+                       T_thresh, rays_alive, rays_t, ray_slab, t_next, sigmas, rgbs, normals, deltas, weights_sum, depth,
+                       image, normal);
+    return launch_status();
+}
+
+int mi3d_compact_alive_ctl2(int32_t *ctl, const int32_t *rays_alive_in, int32_t *rays_alive_out, uint32_t N,
+                            uint32_t max_steps, void *stream) {
+    if (N == 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_compact_alive_ctl<true>, dim3(1), dim3(1024), 0, as_stream(stream), ctl, rays_alive_in,
+                       rays_alive_out, N, 0u, max_steps);
     return launch_status();
 }
 

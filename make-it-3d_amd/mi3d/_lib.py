@@ -36,6 +36,10 @@ _SIGNATURES = {
     "mi3d_march_rays_ctl": [vp, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp],
     "mi3d_composite_rays_ctl": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mi3d_compact_alive_ctl": [vp, vp, vp, u32, u32, u32, vp],
+    "mi3d_infer_begin2": [vp, vp, u32, u32, u32, u32, vp],
+    "mi3d_march_rays_compact_ctl": [vp, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_composite_rays_compact_ctl": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi3d_compact_alive_ctl2": [vp, vp, vp, u32, u32, vp],
     # Part 2 ------------------------------------------------------------------------------------------
     "mi3d_hashgrid_forward": [vp, u32, vp, u32, u32, f32, u32, vp, vp],
     "mi3d_hashgrid_backward": [vp, u32, vp, u32, u32, f32, u32, vp, vp],

@@ -161,9 +161,11 @@ class NeRFNetwork(NeRFRenderer):
         normals_jitter = self._normal_from(sig[:, 7:13]) if x2 is not None else None
         return sig[:, 0], albedo, normals, normals_jitter
 
-    def shade(self, albedo, normal, light_d, ratio, shading):
-        """network_tcnn.py:146-168, including the silent skip of shading for batches of >= 1e6 samples."""
-        if shading == "albedo" or normal.shape[0] >= 1e6:
+    def shade(self, albedo, normal, light_d, ratio, shading, batch_rows=None):
+        """network_tcnn.py:146-168, including the silent skip of shading for batches of >= 1e6 samples.  `batch_rows`:
+        the size of the batch the REFERENCE would have handed over where the buffers here are larger than it (the
+        compact inference rounds evaluate a buffer of `budget` rows; the reference's eval batches hold <= N + 128)."""
+        if shading == "albedo" or (normal.shape[0] if batch_rows is None else batch_rows) >= 1e6:
             return albedo
         lambertian = ratio + (1 - ratio) * (normal @ light_d).clamp(min=0.1)
         if shading == "textureless":
@@ -182,7 +184,7 @@ class NeRFNetwork(NeRFRenderer):
             sigma, albedo, normal = field_ops.field_rows(self.encoder.params, self.sigma_net.net, x.reshape(-1, 3), offs,
                                                          self.encoder.cfg, float(self.bound), self.opt.blob_density,
                                                          self.opt.blob_radius, rows)
-            return sigma, self.shade(albedo, normal, l, ratio, shading), normal
+            return sigma, self.shade(albedo, normal, l, ratio, shading, getattr(self, "_infer_shade_rows", None)), normal
         sigma, albedo, normal, _ = self.field_stencil(x)
         return sigma, self.shade(albedo, normal, l, ratio, shading), normal
 

@@ -239,9 +239,20 @@ class NeRFRenderer(nn.Module):
         return out
 
     # --- the inference loop (renderer.py:526-551), driven from the device ------------------------------------------
-    # rounds per captured graph (0 = launch every round from the host and read the alive count back every 8 rounds, the
-    # round-3 loop).  An even number: the alive / spare lists swap every round.
+    # "budget" (default): compact rounds under a row budget - a round takes n_step = clamp(budget / n_alive, 1,
+    # max_steps) steps of every alive ray, packed into one slab per ray (raymarching.*_compact_ctl): a 128 x 128 render is
+    # a handful of rounds, one or two graph replays, no row of a finished ray is evaluated.  "reference": the reference's
+    # own round structure (n_step = clamp(N // n_alive, 1, 8), rows at n * n_step) on the device control block, bit-
+    # identical to the reference's host loop round by round - what the kernel-level parity tests run, and what renders
+    # of >= 10^6 rays with a shading that looks at normals use (network_tcnn.py:159 skips the shading per BATCH of >= 10^6
+    # rows, and the reference's batches are its rounds).
+    infer_schedule = "budget"
+    infer_budget_rows = None     # rows per round; None: min(max(16 N, 2^18), max(2^21, 2 N))
+    infer_budget_rounds = 4      # rounds per captured graph (budget schedule); 0 = launched from the host, one read per round
+    # rounds per captured graph of the reference schedule (0 = launch every round from the host and read the alive count
+    # back every 8 rounds, the round-3 loop).  An even number: the alive / spare lists swap every round.
     infer_graph_rounds = 32
+    infer_max_graphs = 6         # captured graphs kept per ray count (they share one memory pool)
 
     def _infer_round(self, st, n_ub, light_d, ambient_ratio, shading, dt_gamma, max_steps, T_thresh):
         """One round of the reference loop - march n_step steps for every alive ray, evaluate the field on those rows,
@@ -267,45 +278,121 @@ class NeRFRenderer(nn.Module):
         raymarching.compact_alive_ctl(st["ctl"], alive, spare, N, align, max_steps)
         st["parity"] ^= 1
 
-    def _infer_state(self, N, device, perturb):
+    def _infer_round_budget(self, st, light_d, ambient_ratio, shading, dt_gamma, max_steps, T_thresh):
+        """One compact round: every alive ray marches ctl's n_step steps into its own slab (ctl[2] = the rows the round
+        really has), the field runs on those rows, every ray composites its slab, the alive list is compacted and the
+        next round planned - all launched for N rays and the buffers' capacity; the kernels read the counts."""
+        N = st["N"]
+        alive, spare = (st["alive"], st["spare"]) if st["parity"] == 0 else (st["spare"], st["alive"])
+        raymarching.march_rays_compact_ctl(st["ctl"], N, alive, st["rays_t"], st["rays_o"], st["rays_d"], self.bound,
+                                           self.density_bitfield, self.cascade, self.grid_size, st["fars"], st["xyzs"],
+                                           st["dirs"], st["deltas"], st["ray_slab"], st["t_next"], st["noises"], dt_gamma,
+                                           max_steps)
+        self._infer_rows = st["ctl"][2:3]
+        # network_tcnn.py:159 skips lambertian / textureless / normal shading for a BATCH of >= 10^6 rows; the reference's
+        # eval batches hold at most N (+ padding) rows - the rule must see that, not this round's buffer capacity
+        self._infer_shade_rows = N
+        try:
+            sigmas, rgbs, normals = self(st["xyzs"], st["dirs"], light_d, ratio=ambient_ratio, shading=shading)
+        finally:
+            self._infer_rows = None
+            self._infer_shade_rows = None
+        raymarching.composite_rays_compact_ctl(st["ctl"], N, alive, st["rays_t"], st["ray_slab"], st["t_next"], sigmas,
+                                               rgbs, (normals + 1) / 2, st["deltas"], st["weights_sum"], st["depth"],
+                                               st["image"], st["normal"], T_thresh)
+        raymarching.compact_alive_ctl2(st["ctl"], alive, spare, N, max_steps)
+        st["parity"] ^= 1
+
+    def _infer_state(self, N, device, perturb, rows_cap=None):
         """Caller-owned buffers of the loop for N rays, kept across renders: a captured graph of rounds holds their
         addresses."""
         cache = _INFER_CACHES.setdefault(self, {})   # (not an attribute: copy.deepcopy(model) must not meet a CUDAGraph)
-        st = cache.get((N, str(device)))
+        align = 128
+        rows_cap = N + 2 * align if rows_cap is None else int(rows_cap)
+        key = (N, str(device), rows_cap)
+        st = cache.get(key)
         if st is None:
-            align = 128
-            rows_cap = N + 2 * align
             f32 = dict(dtype=torch.float32, device=device)
-            st = {"N": N, "align": align, "graphs": {},
+            i32 = dict(dtype=torch.int32, device=device)
+            st = {"N": N, "align": align, "rows_cap": rows_cap, "graphs": {}, "pool": None,
                   "rays_o": torch.empty(N, 3, **f32), "rays_d": torch.empty(N, 3, **f32),
                   "fars": torch.empty(N, **f32), "rays_t": torch.empty(N, **f32), "light_d": torch.empty(3, **f32),
                   "xyzs": torch.zeros(rows_cap, 3, **f32), "dirs": torch.zeros(rows_cap, 3, **f32),
                   "deltas": torch.zeros(rows_cap, 2, **f32), "noise_buf": torch.zeros(N, **f32),
-                  "ctl": torch.zeros(8, dtype=torch.int32, device=device),
-                  "alive": torch.empty(N, dtype=torch.int32, device=device),
-                  "spare": torch.empty(N, dtype=torch.int32, device=device),
+                  "ctl": torch.zeros(8, **i32), "alive": torch.empty(N, **i32), "spare": torch.empty(N, **i32),
+                  "ray_slab": torch.zeros(N, 2, **i32), "t_next": torch.zeros(N, **f32),
                   "weights_sum": torch.zeros(N, **f32), "depth": torch.zeros(N, **f32),
                   "image": torch.zeros(N, 3, **f32), "normal": torch.zeros(N, 3, **f32)}
             cache.clear()                       # one ray count at a time: the buffers of an older one are released
-            cache[(N, str(device))] = st
+            cache[key] = st
         st["noises"] = st["noise_buf"] if perturb else None
         st["parity"] = 0
         return st
 
+    def _graph_key_tail(self, shading, ambient_ratio, dt_gamma, max_steps, T_thresh, perturb):
+        """Everything a captured round bakes in besides the buffers: the scalars handed to the kernels (bound, cascade,
+        grid size included - ADVICE round 4), the autocast state AND dtype, and the addresses of bitfield and weights."""
+        ac = torch.is_autocast_enabled("cuda")
+        return (shading, float(ambient_ratio), float(dt_gamma), int(max_steps), float(T_thresh), bool(perturb), ac,
+                str(torch.get_autocast_dtype("cuda")) if ac else None, float(self.bound), int(self.cascade),
+                int(self.grid_size), self.density_bitfield.data_ptr(), tuple(p.data_ptr() for p in self.parameters()))
+
+    def _capture_rounds(self, st, key, rounds, one_round):
+        """`rounds` rounds as one torch.cuda.CUDAGraph over the loop's buffers.  Two eager rounds first (real rounds: they
+        advance the loop): every kernel of a round has then run in this process, so the capture meets no first-use
+        initialisation; two, so the alive / spare lists keep their parity.  The graphs of one ray count share a memory
+        pool (their temporaries are dead when a replay ends and replays never overlap) and at most `infer_max_graphs` of
+        them are kept."""
+        from . import grid_ops
+        for _ in range(2):
+            one_round()
+        profile, grid_ops.PROFILE = grid_ops.PROFILE, None   # (no event records inside a capture)
+        try:
+            if st["pool"] is None:
+                st["pool"] = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local"):
+                for _ in range(rounds):
+                    one_round()
+        finally:
+            grid_ops.PROFILE = profile
+        graphs = st["graphs"]
+        for k in [k for k in graphs if k[-1] != key[-1]]:     # stale: other weights / bitfield / settings
+            del graphs[k]
+        while len(graphs) >= max(1, int(self.infer_max_graphs)):
+            del graphs[next(iter(graphs))]                     # the oldest capture goes
+        graphs[key] = g
+        return g
+
+    def budget_rows(self, N):
+        """Rows a compact round may hold: enough that the first round takes ~16 steps of every ray, bounded so that the
+        field's planes for one round stay around 2 GB (~1 KB per row in fp32)."""
+        if self.infer_budget_rows is not None:
+            return max(int(self.infer_budget_rows), 1)
+        return min(max(16 * N, 1 << 18), max(1 << 21, 2 * N))
+
     def _infer_loop(self, rays_o, rays_d, nears, fars, light_d, ambient_ratio, shading, perturb, dt_gamma, max_steps,
                     T_thresh):
         """The reference loop (renderer.py:526-551) with its per-round state - n_alive, n_step, the alive list, the row
-        count - kept on the DEVICE (raymarching.*_ctl, C ABI Part 1b) and the HOST OUT OF THE LOOP: `infer_graph_rounds`
-        rounds are captured once as a hipGraph (torch.cuda.CUDAGraph: march_ctl -> counted gather / MLP / head ->
-        composite_ctl -> compact_ctl, x 32) per upper bound of the alive count (N, N/2, N/4, ...), and replayed until a
-        single end-of-batch read of the control block says no ray is alive: one D2H per 32 rounds instead of one boolean-
-        mask synchronisation per round in the reference (one per 8 rounds in round 3).  Rounds that run after the last
-        ray died see n_alive = 0 on the device and do nothing.  Same kernels, same round structure, same results as the
-        host-launched loop (tests/test_raymarching_gpu.py compares the two bit for bit)."""
+        count - kept on the DEVICE (raymarching.*_ctl, C ABI Part 1b) and the HOST OUT OF THE LOOP: rounds are captured
+        as hipGraphs (torch.cuda.CUDAGraph: march -> counted gather / MLP / head -> composite -> compaction) and
+        replayed until a single end-of-replay read of the control block says no ray is alive.  Rounds that run after the
+        last ray died see n_alive = 0 on the device and do nothing.  Schedules: see `infer_schedule` above."""
         N, device = rays_o.shape[0], rays_o.device
-        R = int(self.infer_graph_rounds)
-        use_graph = R > 0 and R % 2 == 0 and rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
-        st = self._infer_state(N, device, perturb)
+        # (perturb in eval mode - the reference's own eval / test steps never ask for it, nerf/utils.py:589,596 - shifts
+        # every round after the first back by the jitter in the reference, because its composite's running t starts at
+        # `near`, not at the jittered t0 (raymarching.cu:1070): a quirk of ITS round structure, kept by running it)
+        budget_mode = (self.infer_schedule == "budget" and not perturb
+                       and not (N + 128 >= 1_000_000 and shading != "albedo"))
+        capturing = rays_o.is_cuda and torch.cuda.is_current_stream_capturing()
+        stats = {"schedule": "budget" if budget_mode else "reference", "rounds_launched": 0, "host_reads": 0,
+                 "graph_replays": 0, "graphs_captured": 0}
+        if budget_mode:
+            budget = self.budget_rows(N)
+            st = self._infer_state(N, device, perturb, rows_cap=max(budget, N) + 128)
+            stats["budget_rows"] = budget
+        else:
+            st = self._infer_state(N, device, perturb)
         st["rays_o"].copy_(rays_o)
         st["rays_d"].copy_(rays_d)
         st["fars"].copy_(fars)
@@ -315,58 +402,75 @@ class NeRFRenderer(nn.Module):
             st["noise_buf"].copy_(torch.rand(N, dtype=torch.float32, device=device))
         for k in ("weights_sum", "depth", "image", "normal"):
             st[k].zero_()
-        raymarching.infer_begin(N, device, st["align"], st["ctl"], st["alive"])
         args = (st["light_d"], float(ambient_ratio), shading, float(dt_gamma), int(max_steps), float(T_thresh))
-        stats = {"rounds_launched": 0, "host_reads": 0, "graph_replays": 0, "graphs_captured": 0}
+        state = [N, 0, 0, 0, 0, 0, 0, 0]
+        key_tail = self._graph_key_tail(shading, ambient_ratio, dt_gamma, max_steps, T_thresh, perturb)
 
-        if not use_graph:
-            sync_every = 8
-            n_ub, done_lb, since_sync, next_sync = N, 0, 0, sync_every
-            while n_ub > 0 and done_lb < max_steps:
-                self._infer_round(st, n_ub, *args)
-                stats["rounds_launched"] += 1
-                done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
-                since_sync += 1
-                if since_sync >= next_sync:
-                    state = st["ctl"].tolist()           # the only synchronisation
+        if budget_mode:
+            raymarching.infer_begin2(N, device, budget, 1, int(max_steps), st["ctl"], st["alive"])
+            R = int(self.infer_budget_rounds)
+            one_round = lambda: self._infer_round_budget(st, *args)   # noqa: E731
+            if R <= 0 or R % 2 or capturing or not rays_o.is_cuda:
+                alive = N
+                while alive > 0:
+                    one_round()
+                    stats["rounds_launched"] += 1
+                    state = st["ctl"].tolist()
+                    alive = state[0]
                     stats["host_reads"] += 1
-                    # while rays are dying quickly the host's bound goes stale quickly (and every round evaluates the
-                    # field on its rows_ub rows): read the count back every round then, every `sync_every` otherwise
-                    next_sync = 1 if 4 * state[0] < 3 * n_ub else sync_every
-                    n_ub, done_lb, since_sync = state[0], state[3], 0
+            else:
+                key = ("budget", budget, R, key_tail)
+                alive = N
+                while alive > 0:
+                    g = st["graphs"].get(key)
+                    if g is None:
+                        g = self._capture_rounds(st, key, R, one_round)
+                        stats["rounds_launched"] += 2
+                        stats["graphs_captured"] += 1
+                    g.replay()
+                    stats["rounds_launched"] += R
+                    stats["graph_replays"] += 1
+                    state = st["ctl"].tolist()               # the only synchronisation: once per replay
+                    alive = state[0]
+                    stats["host_reads"] += 1
         else:
-            from . import grid_ops
-            key_tail = (shading, float(ambient_ratio), float(dt_gamma), int(max_steps), float(T_thresh), bool(perturb),
-                        torch.is_autocast_enabled("cuda"), self.density_bitfield.data_ptr(),
-                        tuple(p.data_ptr() for p in self.parameters()))
-            alive = N
-            while alive > 0:
-                n_ub = N
-                while n_ub // 2 >= max(alive, 1024):     # the smallest bucket N / 2^k (>= 1024) that covers the alive count
-                    n_ub //= 2
-                g = st["graphs"].get((n_ub,) + key_tail)
-                if g is None:
-                    # two eager rounds first (real rounds: they advance the loop): every kernel of a round has then run
-                    # in this process, so the capture meets no first-use initialisation; two, so the lists' parity holds
-                    for _ in range(2):
-                        self._infer_round(st, n_ub, *args)
-                    stats["rounds_launched"] += 2
-                    profile, grid_ops.PROFILE = grid_ops.PROFILE, None   # (no event records inside a capture)
-                    try:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                            for _ in range(R):
-                                self._infer_round(st, n_ub, *args)
-                    finally:
-                        grid_ops.PROFILE = profile
-                    st["graphs"] = {k: v for k, v in st["graphs"].items() if k[1:] == key_tail}  # stale keys: other weights
-                    st["graphs"][(n_ub,) + key_tail] = g
-                    stats["graphs_captured"] += 1
-                g.replay()
-                stats["rounds_launched"] += R
-                stats["graph_replays"] += 1
-                alive = st["ctl"].tolist()[0]            # the only synchronisation: once per R rounds
-                stats["host_reads"] += 1
+            raymarching.infer_begin(N, device, st["align"], st["ctl"], st["alive"])
+            R = int(self.infer_graph_rounds)
+            use_graph = R > 0 and R % 2 == 0 and rays_o.is_cuda and not capturing
+            if not use_graph:
+                sync_every = 8
+                n_ub, done_lb, since_sync, next_sync = N, 0, 0, sync_every
+                while n_ub > 0 and done_lb < max_steps:
+                    self._infer_round(st, n_ub, *args)
+                    stats["rounds_launched"] += 1
+                    done_lb += max(min(N // n_ub, 8), 1)     # the device's n_step is at least this
+                    since_sync += 1
+                    if since_sync >= next_sync:
+                        state = st["ctl"].tolist()           # the only synchronisation
+                        stats["host_reads"] += 1
+                        # while rays are dying quickly the host's bound goes stale quickly (and every round evaluates the
+                        # field on its rows_ub rows): read the count back every round then, every `sync_every` otherwise
+                        next_sync = 1 if 4 * state[0] < 3 * n_ub else sync_every
+                        n_ub, done_lb, since_sync = state[0], state[3], 0
+            else:
+                alive = N
+                while alive > 0:
+                    n_ub = N
+                    while n_ub // 2 >= max(alive, 1024):     # the smallest bucket N / 2^k (>= 1024) that covers the alive count
+                        n_ub //= 2
+                    key = ("reference", n_ub, R, key_tail)
+                    g = st["graphs"].get(key)
+                    if g is None:
+                        g = self._capture_rounds(st, key, R, lambda: self._infer_round(st, n_ub, *args))
+                        stats["rounds_launched"] += 2
+                        stats["graphs_captured"] += 1
+                    g.replay()
+                    stats["rounds_launched"] += R
+                    stats["graph_replays"] += 1
+                    state = st["ctl"].tolist()               # the only synchronisation: once per R rounds
+                    alive = state[0]
+                    stats["host_reads"] += 1
+        stats["rounds_done"] = state[4]
         self.infer_stats = stats
         return st["weights_sum"].clone(), st["depth"].clone(), st["image"].clone(), st["normal"].clone()
 

@@ -61,9 +61,14 @@ def regularisers(opt, outputs, pred_ws, is_large=False, past_diff_iters=True):
 
 
 def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, depth_scale, H, W, opt,
-                   shading="albedo", ambient_ratio=1.0, sds_backward="single", t=None, grad_sync=None):
-    """Returns the (unscaled) regulariser loss tensor.  `grad_sync` (callable or None) runs between backward and
-    the optimizer step - the data-parallel all-reduce hook."""
+                   shading="albedo", ambient_ratio=1.0, sds_backward="single", t=None, grad_sync=None, clip_model=None,
+                   ref_rgb=None, ref_text=None):
+    """Returns the (unscaled) loss tensor.  `grad_sync` (callable or None) runs between backward and the optimizer step -
+    the data-parallel all-reduce hook.  `clip_model`, `ref_rgb`, `ref_text` ("reference" schedule only): what the
+    guidance's OTHER branch needs - for t/1000 <= 0.4 on a view that is not `is_large` guidance.train_step takes one
+    DDIM step, decodes, and returns 10 x (CLIP image-image + image-text) similarity of the DENOISED image as a loss value
+    (nerf/sd.py:153-159; decoded under no_grad: a constant w.r.t. the NeRF) which the trainer adds to the regularisers
+    (nerf/utils.py:515-516); no SDS gradient is injected on such a step."""
     from .grid_ops import phase
     optimizer.zero_grad(set_to_none=False)
     B = rays_o.shape[0]
@@ -76,8 +81,11 @@ def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, d
             pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
             pred_ws = outputs["weights_sum"].reshape(B, 1, H, W)
         with phase("guidance_train_step"):  # VAE encode + U-Net x2 (+ NeRF backward #1 in the reference schedule)
+            guidance_loss = 0
             if sds_backward == "reference":
-                guidance.train_step(text_z, pred_rgb, guidance_scale=opt.guidance_scale, t=t)  # NeRF backward #1
+                # NeRF backward #1 inside (t/1000 > 0.4), or the denoise + CLIP branch's loss value (no backward)
+                guidance_loss, _ = guidance.train_step(text_z, pred_rgb, ref_rgb=ref_rgb, ref_text=ref_text,
+                                                       clip_model=clip_model, guidance_scale=opt.guidance_scale, t=t)
                 sds_term = None
             elif sds_backward == "overlapped":
                 latents, finish_guidance = guidance.sds_gradient_async(text_z, pred_rgb, opt.guidance_scale, t)
@@ -87,6 +95,8 @@ def sds_train_step(model, guidance, text_z, optimizer, scaler, rays_o, rays_d, d
                 sds_term = (latents.float() * grad.float()).sum()
         with phase("regularisers_backward"):
             loss = regularisers(opt, outputs, pred_ws)
+            if torch.is_tensor(guidance_loss):
+                loss = guidance_loss + loss       # utils.py:515-516: `loss` starts as the guidance's return value
     with phase("regularisers_backward"):
         total = scaler.scale(loss)
         if sds_term is not None:

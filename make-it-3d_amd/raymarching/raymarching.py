@@ -351,3 +351,56 @@ def compact_alive_ctl(ctl, rays_alive_in, rays_alive_out, N, align=128, max_step
     L.launch("mi3d_compact_alive_ctl", ctl, L.ptr(ctl), L.ptr(L.dev_typed(rays_alive_in, "rays_alive_in", torch.int32)),
              L.ptr(L.dev_typed(rays_alive_out, "rays_alive_out", torch.int32)), int(N), int(max(align, 0)),
              int(max_steps))
+
+
+# ---- the same loop in compact rounds under a row budget (C ABI Part 1b, second half; csrc/raymarching.hip) ---------------
+# A round takes n_step = clamp(budget / n_alive, step_min, step_max) steps of every alive ray and the march packs what the
+# rays really emitted into one slab per ray: a 128 x 128 render is a handful of rounds instead of ~280, and rays that
+# missed, finished or terminated cost no rows.  ctl[2] is the round's row count (written by the march).
+
+
+def infer_begin2(N, device, budget_rows, step_min=1, step_max=1024, ctl=None, rays_alive=None):
+    if ctl is None:
+        ctl = torch.zeros(8, dtype=torch.int32, device=device)
+    else:
+        L.dev_typed(ctl, "ctl", torch.int32).zero_()
+    if rays_alive is None:
+        rays_alive = torch.empty(N, dtype=torch.int32, device=device)
+    L.dev_typed(rays_alive, "rays_alive", torch.int32)
+    L.launch("mi3d_infer_begin2", ctl, L.ptr(ctl), L.ptr(rays_alive), int(N), int(budget_rows), int(step_min), int(step_max))
+    return ctl, rays_alive
+
+
+def march_rays_compact_ctl(ctl, n_alive_max, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, fars, xyzs,
+                           dirs, deltas, ray_slab, t_next, noises=None, dt_gamma=0, max_steps=1024):
+    """Up to ctl's n_step occupied steps of every alive ray into ONE slab per ray of the caller-owned sample buffers:
+    ray_slab int32[>= n_alive_max, 2] = (first row, rows), t_next f32[>= n_alive_max] = where the ray's march stands;
+    ctl[2] = the rows of the round."""
+    rays_o, rays_d = _rays(rays_o, rays_d)
+    bits = L.dev_typed(density_bitfield, "density_bitfield", torch.uint8)
+    rows_cap = min(xyzs.shape[0], dirs.shape[0], deltas.shape[0])
+    if ray_slab.shape[0] < n_alive_max or t_next.shape[0] < n_alive_max:
+        raise L.Mi3dError("ray_slab / t_next hold fewer slots than n_alive_max")
+    L.launch("mi3d_march_rays_compact_ctl", rays_o, L.ptr(L.dev_typed(ctl, "ctl", torch.int32)), int(n_alive_max),
+             L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")), L.ptr(rays_o),
+             L.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), int(C), int(H), L.ptr(bits),
+             L.ptr(L.dev_f32(fars, "fars")), int(rows_cap), L.ptr(L.dev_f32(xyzs, "xyzs", 3)),
+             L.ptr(L.dev_f32(dirs, "dirs", 3)), L.ptr(L.dev_f32(deltas, "deltas", 2)),
+             L.ptr(L.dev_typed(ray_slab, "ray_slab", torch.int32)), L.ptr(L.dev_f32(t_next, "t_next")), L.ptr(noises))
+
+
+def composite_rays_compact_ctl(ctl, n_alive_max, rays_alive, rays_t, ray_slab, t_next, sigmas, rgbs, normals, deltas,
+                               weights_sum, depth, image, normal, T_thresh=1e-2):
+    sigmas = L.dev_f32(sigmas.float().contiguous(), "sigmas")
+    rgbs = L.dev_f32(rgbs.float().contiguous(), "rgbs")
+    normals = L.dev_f32(normals.float().contiguous(), "normals")
+    L.launch("mi3d_composite_rays_compact_ctl", sigmas, L.ptr(ctl), int(n_alive_max), float(T_thresh),
+             L.ptr(L.dev_typed(rays_alive, "rays_alive", torch.int32)), L.ptr(L.dev_f32(rays_t, "rays_t")),
+             L.ptr(L.dev_typed(ray_slab, "ray_slab", torch.int32)), L.ptr(L.dev_f32(t_next, "t_next")), L.ptr(sigmas),
+             L.ptr(rgbs), L.ptr(normals), L.ptr(L.dev_f32(deltas, "deltas")), L.ptr(L.dev_f32(weights_sum, "weights_sum")),
+             L.ptr(L.dev_f32(depth, "depth")), L.ptr(L.dev_f32(image, "image")), L.ptr(L.dev_f32(normal, "normal")))
+
+
+def compact_alive_ctl2(ctl, rays_alive_in, rays_alive_out, N, max_steps=1024):
+    L.launch("mi3d_compact_alive_ctl2", ctl, L.ptr(ctl), L.ptr(L.dev_typed(rays_alive_in, "rays_alive_in", torch.int32)),
+             L.ptr(L.dev_typed(rays_alive_out, "rays_alive_out", torch.int32)), int(N), int(max_steps))

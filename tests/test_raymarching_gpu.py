@@ -18,7 +18,7 @@ def T(a, dev):
 
 def test_loads_native_library(cuda):
     from mi3d import _lib
-    assert _lib.lib().mi3d_abi_version() == 3
+    assert _lib.lib().mi3d_abi_version() == 4
 
 
 def test_near_far_bit_exact(cuda, oracle):
