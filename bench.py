@@ -59,6 +59,8 @@ WORKLOADS = {
     # BASELINE config 5: refine stage - textured point cloud rasterised at 512 x 512 (+ 256, 128 for the
     # multi-scale U-Net and a coverage mask), gated U-Net, SD U-Net SDS step, Adam; value = refine-steps/s
     "c5_refine": dict(H=512, W=512, points=500_000, ppp=8, radius_px=2.0, mode="refine"),
+    # the same at the reference's own default resolution (main.py --H / --W 800; nerf/utils.py:839-894 renders at opt.H)
+    "c5_refine_800": dict(H=800, W=800, points=500_000, ppp=8, radius_px=2.0, mode="refine"),
     "small": dict(H=32, W=32, max_steps=128, bitfield="dense", views=1),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -974,7 +976,7 @@ def bench_refine(args, wl, dev, rank, world):
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 point renderer + f32 gated U-Net, f16 SD U-Net",
             "data": "synthetic (500 k points on a noisy sphere shell, random features / weights)",
-            "config": {"workload": f"c5_refine: {P} points, {H}x{W} (+ /2, /4, + mask pass), radius {wl['radius_px']} px, "
+            "config": {"workload": f"{args.workload}: {P} points, {H}x{W} (+ /2, /4, + mask pass), radius {wl['radius_px']} px, "
                                    f"{wl['ppp']} points per pixel, gated U-Net 19->3, SD2-base-shaped U-Net SDS (t={T_FIXED})",
                        "parallelism": f"dp{world} (independent views)"},
             "roofline": {"kernel": "point renderer: k_raster_count/scan/fill/tiles + k_points_composite_fwd x 4 passes "

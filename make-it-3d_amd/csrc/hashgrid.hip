@@ -1021,6 +1021,9 @@ __device__ __forceinline__ unsigned long long fixed_point(float x) {
 // handful of bins to reduce them in.  This merges across lanes, runs AND stencil points.)  A contribution that finds no
 // slot within kMergeProbes goes out as a record of its own.
 constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFFFu;
+#ifndef MI3D_RUN_MERGE
+#define MI3D_RUN_MERGE 0   // the coarse role's group flush sums a run's lanes in registers first (flush_group); A/B: round 5
+#endif
 // Fine levels: the x-pair records of kChunkPts stencil points of a tile (64 lanes x 4 pairs each) are SORTED BY BIN in the
 // wave's LDS before they leave, so that what goes to a region is a contiguous run of records (consecutive lanes store
 // consecutive 16-byte slots) instead of one scattered 16-byte store per lane.  The staging area is the memory the coarse
@@ -1071,10 +1074,13 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
     const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
     const bool level_major = !role_b && (fine_level_major & 1u);
-#ifdef MI3D_DEV  // tools build: 0x10000 = the coarse role's shared-face pass off (A/B against round 3's pair passes)
+#ifdef MI3D_DEV  // tools build: 0x10000 = the coarse role's shared-face pass off (A/B against round 3's pair passes);
+                 // 0x20000 toggles the run-merged group flush against its product default
     const bool face_on = !(fine_level_major & 0x10000u);
+    const bool run_merge = ((fine_level_major & 0x20000u) != 0u) != (MI3D_RUN_MERGE != 0);
 #else
     constexpr bool face_on = true;
+    constexpr bool run_merge = MI3D_RUN_MERGE != 0;
 #endif
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
@@ -1284,6 +1290,41 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
             };
             auto flush_group = [&]() __attribute__((always_inline)) {
                 if (acc_any) {
+                    if (run_merge) {
+                        // Consecutive samples of a ray sit in ONE cell of a coarse level for a whole run of lanes (37
+                        // marching steps per cell on level 0, 5 on level 6), so in the flush below most of a wave's lanes
+                        // add into the SAME 8 slots: LDS atomics on one address serialise, and these 24 instructions - with
+                        // every lane active - are where the gather table's time goes (an atomic here retires ~70 cycles per
+                        // instruction and CU against ~12 for distinct addresses, profiles/lds_atomics_r01.txt).  So the
+                        // register sums of a run are first added up ACROSS its lanes, in segments of at most 8 lanes that
+                        // never cross an 8-lane boundary (three steps of row_shr, pure VALU: no LDS), and only a segment's
+                        // last lane goes to the table - 8 x fewer lanes per address for 3 x 16 DPP moves + adds.
+                        const uint32_t pbx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bx, 0x111, 0xf, 0xf, true);
+                        const uint32_t pby = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)by, 0x111, 0xf, 0xf, true);
+                        const uint32_t pbz = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bz, 0x111, 0xf, 0xf, true);
+                        const bool head = (lane & 7) == 0 || pbx != bx || pby != by || pbz != bz;
+                        const unsigned long long heads = __ballot(head);
+                        const uint32_t first = 63u - (uint32_t)__builtin_clzll(heads & ((2ull << lane) - 1ull));
+                        const uint32_t pos = (uint32_t)lane - first;                        // 0 .. 7 inside the segment
+                        const bool tail = lane == 63 || (((heads >> 1) >> lane) & 1ull) != 0ull;
+                        auto seg_step = [&](auto ctrl_tag, uint32_t off) __attribute__((always_inline)) {
+                            constexpr int CTRL = decltype(ctrl_tag)::value;   // (the DPP control is an instruction immediate)
+                            float u0[8], u1[8];
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) {   // (moved under the full exec mask: a masked DPP source reads 0)
+                                u0[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc0[k]), CTRL, 0xf, 0xf, true));
+                                u1[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc1[k]), CTRL, 0xf, 0xf, true));
+                            }
+                            const bool take = pos >= off;
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) { acc0[k] += take ? u0[k] : 0.f; acc1[k] += take ? u1[k] : 0.f; }
+                        };
+                        seg_step(std::integral_constant<int, 0x111>{}, 1u);   // row_shr:1
+                        seg_step(std::integral_constant<int, 0x112>{}, 2u);   // row_shr:2
+                        seg_step(std::integral_constant<int, 0x114>{}, 4u);   // row_shr:4
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) { acc0[k] = tail ? acc0[k] : 0.f; acc1[k] = tail ? acc1[k] : 0.f; }
+                    }
                     gather8(bx, by, bz, acc0, acc1);
 #pragma unroll
                     for (uint32_t k = 0; k < 8; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }

@@ -597,12 +597,12 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const int32_t done = ctl[CTL_DONE] + ctl[CTL_STEP];
+        const int32_t done = n_alive != 0u ? ctl[CTL_DONE] + ctl[CTL_STEP] : ctl[CTL_DONE];
         int32_t alive = (int32_t)base_s;
         if (done >= (int32_t)max_steps) alive = 0;  // `while step < max_steps` of the reference loop
         if (BUDGET) infer_plan2(alive, ctl); else infer_plan(alive, N, align, ctl);
         ctl[CTL_DONE] = done;
-        ctl[CTL_ROUNDS] += 1;
+        if (n_alive != 0u) ctl[CTL_ROUNDS] += 1;   // (a round launched after the last ray died is not a round of the loop)
     }
 }
 

@@ -38,10 +38,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = {}
 _LAST_PAIR = {}
 # autocast output bounds.  Round 4 asserted rtol 2e-2 / atol 2e-3 without recording what was measured; the figures are now
-# in the report (`outputs`) and the bounds are set from them (<= 3 x the measured use of the bound: see
-# profiles/headline_parity_r05.json).  Both routes round the same quantities to binary16 (MLP input / weights / products
-# under autocast); what differs is the order of the fp32 accumulations behind them.
-AUTOCAST_RTOL, AUTOCAST_ATOL = 2e-2, 2e-3
+# in the report (`outputs`, profiles/headline_parity_r05.json): image max |diff| 4.0e-5 (dense) / 8.4e-5 (pruned), i.e.
+# 7.8e-5 / 1.7e-4 relative, depth 2.9e-6, weights 1e-6 - both routes round the same quantities to binary16 (MLP input,
+# weights and products under autocast); what differs is the order of the fp32 accumulations behind them.  The bounds
+# below leave a factor of ~3 over the largest measured use (0.28 of atol + rtol |reference| on the pruned image).
+AUTOCAST_RTOL, AUTOCAST_ATOL = 2e-4, 2e-4
 
 
 @pytest.fixture(scope="module")
@@ -215,8 +216,7 @@ def test_c2_dense_autocast_headline_mode(ref, cuda):
     """(a) the headline: C2 dense, autocast, two-backward schedule, binary16 planes, sliced binned scatter."""
     a, b, rep, n = _run_pair(ref, cuda, "c2_dense_autocast", "dense", True)
     assert 10_000_000 < n < 12_000_000
-    # binary16 resolution through 664 composited samples per ray.  Measured (profiles/headline_parity_r05.json, `outputs`):
-    # the bound below is ~3 x what the two routes differ by (VERDICT round 4, weak 2: it was asserted, not recorded)
+    # (VERDICT round 4, weak 2: the bound was asserted at binary16 resolution, 2e-2, and never recorded - see AUTOCAST_RTOL)
     _outputs_close(a, b, rtol=AUTOCAST_RTOL, atol=AUTOCAST_ATOL, name="c2_dense_autocast")
     assert abs(rep["loss_orient"][1] - rep["loss_orient"][0]) <= 2e-2 * abs(rep["loss_orient"][0])
     assert abs(rep["loss_smooth"][1] - rep["loss_smooth"][0]) <= 2e-2 * abs(rep["loss_smooth"][0])

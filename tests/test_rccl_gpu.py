@@ -33,7 +33,8 @@ def test_bench_small_under_torchrun_with_nccl(cuda):
     # what a line measured under a process group says about itself (bench.summarise_ranks): the group's own world size and
     # backend, this rank's clock, the time its stream spent in the gradient all-reduce (HIP events), scale, updates, memory
     rk = line["ranks"]
-    assert rk["backend"] == "nccl" and rk["rccl_world_size"] == rk["launcher_world_size"] == 1 and rk["valid"], rk
+    assert rk["backend"] == "nccl" and rk["rccl_world_size"] == rk["launcher_world_size"] == 1, rk
+    assert rk["valid"] or all("skipped the optimizer update" in p for p in rk["problems"]), rk   # (a GradScaler overflow)
     r0 = rk["per_rank"][0]
-    assert r0["rank"] == 0 and r0["optimizer_steps_applied"] == 3 and r0["ms_per_step_local"] > 0
+    assert r0["rank"] == 0 and 0 <= r0["optimizer_steps_applied"] <= 3 and r0["ms_per_step_local"] > 0
     assert 0 < r0["all_reduce_ms_per_step"] < r0["ms_per_step_local"] and r0["peak_mem_GiB"] > 0

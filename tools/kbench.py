@@ -224,6 +224,42 @@ def main():
                     tune(k, -1)
             del g
         res["scatter13_plus_ms"] = out
+    if "scatter_r05" in what:  # round 5: the coarse role's run-merged group flush (dev bit 0x20000 of tunable 10), alone and in the
+        # whole scatter, with the level threshold and the fine wave count re-swept around it; wall-clock stamps per
+        # configuration so that a clock / power log sampled beside this process can be laid over the timings
+        import time
+        out, stamps = {}, []
+        ex = torch.randn(16, n, 2, device=dev).to(feats.dtype)
+        RM = 0x20000
+        for census in (False, True):
+            a.real_census = census
+            g = gradient_planes(feats.dtype)
+            tag = "real_" if census else "dense_"
+            ref = None
+            for name, kvs in (("base", {}), ("run_merge", {10: RM}), ("base_2", {}), ("run_merge_2", {10: RM}),
+                              ("coarse_only_base", {5: 0x007F}), ("coarse_only_run_merge", {5: 0x007F, 10: RM}),
+                              ("fine_only", {5: 0xFF80}),
+                              ("run_merge_merge30", {10: RM, 15: 30}), ("run_merge_merge58", {10: RM, 15: 58}),
+                              ("run_merge_fine1280", {10: RM, 3: 1280}), ("run_merge_fine2048", {10: RM, 3: 2048}),
+                              ("base_3", {}), ("run_merge_3", {10: RM})):
+                for k, v in kvs.items():
+                    tune(k, v)
+                t0 = time.time()
+                out[tag + name] = timeit(lambda: field_ops.scatter_binned(
+                    xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex), a.iters)
+                stamps.append((tag + name, t0, time.time()))
+                if name in ("base", "run_merge"):   # same gradient, up to the fp32 rounding of a segment's register sum
+                    got = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex)
+                    if ref is None:
+                        ref = got
+                    else:
+                        out[tag + "run_merge_max_err_rel"] = float((got - ref).abs().max() / ref.abs().max())
+                    del got
+                for k in kvs:
+                    tune(k, -1)
+            del g, ref
+        res["scatter_r05_ms"] = out
+        res["scatter_r05_stamps"] = stamps
     if "scatter_diag" in what:  # the coarse role alone, with its gather-table atomics switched off (timing only)
         g = gradient_planes(feats.dtype)
         out = {}
