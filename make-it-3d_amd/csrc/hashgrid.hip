@@ -1022,7 +1022,10 @@ __device__ __forceinline__ unsigned long long fixed_point(float x) {
 // slot within kMergeProbes goes out as a record of its own.
 constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFFFu;
 #ifndef MI3D_RUN_MERGE
-#define MI3D_RUN_MERGE 0   // the coarse role's group flush sums a run's lanes in registers first (flush_group); A/B: round 5
+// the coarse role's group flush sums a run's lanes in registers first (flush_group).  Round 5, one box, tools/kbench.py --what
+// scatter_r05, three interleaved pairs each: dense gradients 54.4-54.6 -> 53.3-53.5 ms, real census 37.7-37.8 -> 36.3-36.4;
+// the coarse role alone 36.3 -> 34.2 / 25.9 -> 24.2 (profiles/kbench_r05_scatter_run_merge.json)
+#define MI3D_RUN_MERGE 1
 #endif
 // Fine levels: the x-pair records of kChunkPts stencil points of a tile (64 lanes x 4 pairs each) are SORTED BY BIN in the
 // wave's LDS before they leave, so that what goes to a region is a contiguous run of records (consecutive lanes store

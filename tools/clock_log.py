@@ -17,9 +17,9 @@ def sample():
     rec = {"t": time.time()}
     for k, v in card.items():
         lk = k.lower()
-        if "sclk" in lk:
+        if "sclk" in lk and "level" not in lk:      # "sclk clock speed:": "(2400Mhz)"; "sclk clock level:" is an index
             rec["sclk_mhz"] = num(v)
-        elif "mclk" in lk:
+        elif "mclk" in lk and "level" not in lk:
             rec["mclk_mhz"] = num(v)
         elif "power" in lk and "w" in lk and "power_w" not in rec:
             rec["power_w"] = num(v)
