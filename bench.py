@@ -670,8 +670,8 @@ def main():
                     for prm in clip_model.parameters():
                         prm.requires_grad_(not frozen)
                     step_extra.update(t=300, clip_model=clip_model, ref_rgb=ref_rgb, ref_text="a toy")
-                    try:
-                        e, cprof, cinfo = run("fp32", "reference", args.variant_steps, 1)
+                    try:   # (two warm-up steps: the CLIP towers' weight-gradient kernels are first used here)
+                        e, cprof, cinfo = run("fp32", "reference", args.variant_steps, 2)
                     finally:
                         step_extra.clear()
                         clip_model.zero_grad(set_to_none=True)

@@ -196,6 +196,14 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode(PointSet ps, uint
 // coarse levels, where it applies, are served by the L1 anyway and the extra compares made them 5-15 % slower).
 constexpr uint32_t kXcds = 8;
 constexpr int kMaxSegs = 16;
+#ifndef MI3D_ENCODE_TRIPLE
+// x-group evaluation on the fine hashed levels in a kernel instance of their own (encode_group_hash; VERDICT round 4 item 4:
+// "the x-triple row sharing").  Measured in round 5 (tools/kbench.py --what encode_r05, profiles/kbench_r05_encode_xgroup.json),
+// bit-identical planes: per level 1.44 -> 1.35 ms (level 9), 1.87 -> 1.75 (10), 2.33 -> 2.24 (11), 2.69 -> 2.65 (12), nothing from
+// level 13 on - 0.45 ms over all levels, less than the second launch costs (whole gather 22.3 -> 22.5-23.0 ms).  The fine
+// levels do not speed up in proportion to the lines they no longer ask for: NOT taken; the tools build keeps the switch.
+#define MI3D_ENCODE_TRIPLE 0
+#endif
 
 struct EncodeSeg { uint32_t level, tile0, tile1, wgs; };  // wgs: workgroups of the XCD that walk this segment
 struct EncodePlan {
@@ -347,14 +355,93 @@ __device__ __forceinline__ bool gather_corners_fast(const GridLevel &L, const Le
     return true;
 }
 
+// Stencil points that differ in their x offset only - the sample, its +x and its -x neighbour; the +x / -x pair around the
+// jittered position - have the SAME (y, z) rows on a hashed level: entry = (cx ^ row hash) & mask, and cx +- a few cells
+// changes the low bits only, so the three points' corners of a row lie in the same 128-byte line (16 entries) with
+// probability ~ 1 - d / 16 for d cells of epsilon (level 11: 0.82, level 13: 0.67, level 15: 0.37).  Evaluated one point
+// at a time those lines are fetched from the L2 once PER POINT (a wave's 64 lanes touch ~32 KB of lines per point, twelve
+// waves share a 32 KB L1: nothing survives from one point to the next), and the fine levels are bound by exactly that,
+// the L2 -> L1 line rate.  Here the points of such a group are evaluated TOGETHER, row by row, the loads
+// of one row issued back to back: a request for a line whose miss is still pending merges with it (the mechanism the
+// straddling x + 1 corner already uses, ORDER above).  Same cells, same weights, same order of the fused multiply-adds per
+// point: the planes are bit-identical; the row hash and the (y, z) cell are computed once per group.
+template <bool NT>
+__device__ __forceinline__ void encode_group_hash(const PointSet &ps, const float (&base)[2][3], const GridLevel &L,
+                                                  const LevelFast &F, const float2 *__restrict__ lvl,
+                                                  float *__restrict__ planes, int out_half, size_t plane0, uint32_t n,
+                                                  uint32_t s, uint32_t p, uint32_t g /* 2 or 3, uniform */) {
+    uint32_t cx[3], cy = 0, cz = 0;
+    float fx[3], fy = 0.f, fz = 0.f;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; ++i) {
+        if (i < g) {
+            float q[3];
+            point_of(ps, base, p + i, ps.offs[p + i], q);
+            grid_cell(q[0], L.scale, cx[i], fx[i]);
+            if (i == 0) { grid_cell(q[1], L.scale, cy, fy); grid_cell(q[2], L.scale, cz, fz); }   // (equal for the whole group)
+        } else { cx[i] = 0; fx[i] = 0.f; }
+    }
+    const uint32_t hy = cy * kPrimeY, hz = cz * kPrimeZ, hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
+    const uint32_t yz[4] = {hy ^ hz, hy1 ^ hz, hy ^ hz1, hy1 ^ hz1};
+    const uint32_t slot_mask = F.last & ~1u;
+    float4 t[3][4];
+    float2 u[3][4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i) {
+            if (i < g) {
+                t[i][j] = *reinterpret_cast<const float4 *>(lvl + ((yz[j] ^ cx[i]) & slot_mask));
+                if (cx[i] & 1u) u[i][j] = lvl[(yz[j] ^ (cx[i] + 1u)) & F.last];
+            }
+        }
+    }
+    const float gy = 1.0f - fy, gz = 1.0f - fz;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; ++i) {
+        if (i < g) {
+            const bool cx_odd = cx[i] & 1u;
+            float2 v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const bool e0_odd = (yz[j] ^ cx[i]) & 1u;
+                const float2 lo = make_float2(t[i][j].x, t[i][j].y), hi = make_float2(t[i][j].z, t[i][j].w);
+                v[2 * j] = e0_odd ? hi : lo;
+                v[2 * j + 1] = cx_odd ? u[i][j] : (e0_odd ? lo : hi);
+            }
+            const float gx = 1.0f - fx[i];
+            // weights in tcnn's multiplication order ((1 * wx) * wy) * wz, corners accumulated in its order (encode_points)
+            const float w00 = gx * gy, w10 = fx[i] * gy, w01 = gx * fy, w11 = fx[i] * fy;
+            const float w[8] = {w00 * gz, w10 * gz, w01 * gz, w11 * gz, w00 * fz, w10 * fz, w01 * fz, w11 * fz};
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { r0 += w[k] * v[k].x; r1 += w[k] * v[k].y; }
+            store_plane_pair<NT>(planes, out_half, plane0 + (size_t)(p + i) * n + s, r0, r1);
+        }
+    }
+}
+
 // one (tile, level): the P points of the lane's sample -> plane pairs
-template <int KIND, bool PAIR, bool NT>
+template <int KIND, bool PAIR, bool NT, bool TRIPLE = false>
 __device__ __forceinline__ void encode_points(const PointSet &ps, const float (&base)[2][3], const GridLevel &L,
                                               const LevelFast &F, const float2 *__restrict__ lvl,
                                               float *__restrict__ planes, int out_half, size_t plane0, uint32_t n,
                                               uint32_t s) {
     float4 o_next = ps.offs[0];
     for (uint32_t p = 0; p < ps.P; ++p) {
+        if (TRIPLE && KIND == kHashPow2 && PAIR && ps.mode == 1) {
+            // how many points from p on differ in their x offset only (uniform: the offsets are kernel arguments)
+            uint32_t g = 1;
+            while (g < 3u && p + g < ps.P && ps.offs[p + g].y == ps.offs[p].y && ps.offs[p + g].z == ps.offs[p].z &&
+                   ((p + g) < ps.P0) == (p < ps.P0))
+                ++g;
+            if (g > 1u) {
+                encode_group_hash<NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s, p, g);
+                p += g - 1u;
+                o_next = ps.offs[p + 1 < ps.P ? p + 1 : p];
+                continue;
+            }
+        }
         float q[3];
         const float4 o = o_next;
         o_next = ps.offs[p + 1 < ps.P ? p + 1 : p];  // (scalar load, a point ahead of its use)
@@ -393,7 +480,7 @@ std::mutex g_slot_mutex;
 __device__ unsigned long long mi3d_dbg_encode[kXcds * (1 + kMaxSegs)];
 #endif
 
-template <bool PAIR, bool NT>
+template <bool PAIR, bool NT, bool TRIPLE = false>
 __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet ps, uint32_t n,
                                                                        const float2 *__restrict__ table, GridTable T,
                                                                        EncodePlan plan, float *__restrict__ planes,
@@ -444,7 +531,7 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
             float base[2][3];
             load_bases(ps, s, true, base);
             if (F.kind == kDense3) encode_points<kDense3, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
-            else if (F.kind == kHashPow2) encode_points<kHashPow2, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
+            else if (F.kind == kHashPow2) encode_points<kHashPow2, PAIR, NT, TRIPLE>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
             else encode_points<kGeneral, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
         }
     }
@@ -514,13 +601,14 @@ inline uint32_t encode_level_wgs_per_cu(double x, uint32_t coarse, uint32_t fine
 // The (level, tile) list cut into kXcds contiguous segments of equal modelled cost.
 inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float step01, int only_level,
                                    uint32_t wgs_coarse_per_xcd, uint32_t wgs_fine_per_xcd, uint32_t first_level = 0,
-                                   int point_mode = 1) {
+                                   int point_mode = 1, uint32_t level_mask = 0xFFFFFFFFu) {
     EncodePlan plan{};
     double cost[MI3D_MAX_LEVELS], total = 0.0;
     for (uint32_t l = 0; l < T.n_levels; ++l) {
         cost[l] = encode_level_cost((double)step01 * (double)T.level[l].scale,
                                     level_fast(T.level[l], point_mode).kind == kDense3);
         if (only_level >= 0) cost[l] = (int)l == only_level ? 1.0 : 0.0;
+        if (!((level_mask >> l) & 1u)) cost[l] = 0.0;  // another launch's levels
         if (l < first_level) cost[l] = 0.0;  // served from LDS by k_grid_encode_planes_lds
         total += cost[l];
     }
@@ -2027,10 +2115,17 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
                            st, ps, n, tab, T, n_lds, out, out_half, count);
         if (n_lds == T.n_levels) return (int)hipGetLastError();
     }
-    const EncodePlan plan = make_encode_plan(T, tiles, step01, only_level, wgs_coarse, wgs_fine, n_lds);
-    const uint32_t per_xcd = wgs_coarse;
-    const dim3 grid(per_xcd * kXcds), block(kWave * kWaves);
-    uint32_t *next = nullptr;
+    // The launch (or launches) of the XCD-planned kernel.  With the x-group evaluation (encode_group_hash, TRIPLE) the fine
+    // levels - hashed, x = cells per marching step >= 0.30: 3 workgroups per CU anyway - go to a kernel instance of their
+    // own: holding three points' rows in flight takes ~2 x the registers, which the coarse levels' 6 workgroups per CU
+    // cannot afford.  Each launch balances its own levels over the XCDs and claims tiles from its own counter slot.
+    uint32_t fine_mask = 0u;
+    for (uint32_t l = n_lds; l < T.n_levels; ++l) {
+        const double x = (double)step01 * (double)T.level[l].scale;
+        if (level_fast(T.level[l], 1).kind == kHashPow2 && encode_level_wgs_per_cu(x, 6u, 3u) == 3u) fine_mask |= 1u << l;
+    }
+    const int triple = MI3D_TUNE(MI3D_T_ENCODE_TRIPLE, MI3D_ENCODE_TRIPLE);
+    const bool split = triple != 0 && fine_mask != 0u && (variant & 3) == 3;
     // One counter slot per launch, a ring of 64, zeroed in-stream right before the kernel; a hipEvent recorded behind the
     // kernel says when the slot is free again.  A slot coming round on the stream that used it last is free by stream
     // order; on any other stream only once its event has completed - otherwise the launch leaves the slot alone and deals
@@ -2039,10 +2134,13 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     // stream's handle is not a valid argument, and a launch captured into a hipGraph recorded the idle capture stream as
     // owner while the graph later replays elsewhere - ADVICE round 4.)  A launch that is being CAPTURED always deals
     // statically: a graph replays any number of times on any stream, it must not own a slot.
-    int slot_used = -1;
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
-    if (MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0 && capturing == hipStreamCaptureStatusNone) {
+    const bool claim_tiles = MI3D_TUNE(MI3D_T_ENCODE_STATIC_TILES, 0) == 0 && capturing == hipStreamCaptureStatusNone;
+    auto acquire_slot = [&](uint32_t *&next, int &slot_used) -> int {
+        next = nullptr;
+        slot_used = -1;
+        if (!claim_tiles) return 0;
         uint32_t *base = nullptr;
         hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_encode_next));
         if (e != hipSuccess) return (int)e;
@@ -2077,21 +2175,42 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
             if (e != hipSuccess) return (int)e;
             slot_used = (int)slot;
         }
-    }
-    auto slot_done = [&]() {   // behind the kernel: the slot's counters are free once this event has completed
+        return 0;
+    };
+    auto slot_done = [&](int slot_used) {   // behind the kernel: the slot's counters are free once this event has completed
         if (slot_used >= 0) {
             std::lock_guard<std::mutex> guard(g_slot_mutex);
             if (hipEventRecord(g_slots[slot_used].done, st) != hipSuccess) (void)hipGetLastError();
         }
     };
-    if ((variant & 3) == 3)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
-    else if (variant & 1)
-        hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
-    else
-        hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
-    const int rc = (int)hipGetLastError();
-    slot_done();
+    const dim3 block(kWave * kWaves);
+    int rc = 0;
+    for (int part = 0; part < (split ? 2 : 1) && rc == 0; ++part) {
+        const uint32_t mask = split ? (part == 0 ? ~fine_mask : fine_mask) : 0xFFFFFFFFu;
+        const EncodePlan plan = make_encode_plan(T, tiles, step01, only_level, wgs_coarse, wgs_fine, n_lds, 1, mask);
+        uint32_t segs = 0;
+        for (uint32_t x = 0; x < kXcds; ++x) segs += plan.n_seg[x];
+        if (segs == 0) continue;   // (no level of this class)
+        const bool fine_part = split && part == 1;
+        const dim3 grid((fine_part ? wgs_fine : wgs_coarse) * kXcds);
+        uint32_t *next = nullptr;
+        int slot_used = -1;
+        rc = acquire_slot(next, slot_used);
+        if (rc != 0) break;
+#if defined(MI3D_DEV) || MI3D_ENCODE_TRIPLE   // (the product is built without the instance: measured, not taken - see MI3D_ENCODE_TRIPLE)
+        if (fine_part)
+            hipLaunchKernelGGL((k_grid_encode_planes<true, true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
+        else
+#endif
+        if ((variant & 3) == 3)
+            hipLaunchKernelGGL((k_grid_encode_planes<true, true>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
+        else if (variant & 1)
+            hipLaunchKernelGGL((k_grid_encode_planes<true, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
+        else
+            hipLaunchKernelGGL((k_grid_encode_planes<false, false>), grid, block, 0, st, ps, n, tab, T, plan, out, out_half, count, next);
+        rc = (int)hipGetLastError();
+        slot_done(slot_used);
+    }
     return rc;
 }
 

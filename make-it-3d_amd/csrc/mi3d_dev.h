@@ -42,4 +42,6 @@ enum : int {
                                    //          marching steps long (product: 42 -> levels 0-6 at C2)
     MI3D_T_ENCODE_LDS_LEVELS = 16, // gather: levels served from LDS (default: as many as fit)
     MI3D_T_ENCODE_STATIC_TILES = 17,  // gather: 1 = tiles dealt statically (round 2's order) instead of claimed
+    MI3D_T_ENCODE_TRIPLE = 18,     // gather: 1 = the fine hashed levels in a launch of their own that evaluates the stencil
+                                   //          points differing in x only (sample, +x, -x) together (encode_group_hash)
 };

@@ -111,6 +111,26 @@ def main():
         res["encode_ms"] = timeit(encode, 5)
         it = torch.int16 if feats.dtype == torch.float16 else torch.int32   # bit-level checksum per level (A/B across builds)
         res["encode_checksum"] = [int(feats[l].view(it).to(torch.int64).sum()) for l in range(feats.shape[0])]
+    if "encode_r05" in what:  # round 5: the x-group evaluation of the fine hashed levels (tunable 18), whole gather and per level
+        tune(18, 0)
+        encode()
+        ref = feats.clone()
+        out = {}
+        for rep in range(3):
+            for v in (0, 1):
+                tune(18, v)
+                feats.zero_()
+                out[f"triple{v}_rep{rep}_ms"] = timeit(encode, a.iters)
+                out[f"triple{v}_rep{rep}_bitexact"] = bool(torch.equal(feats, ref))
+        for l in range(5, 16):
+            tune(T_ENCODE_ONLY_LEVEL, l)
+            for v in (0, 1):
+                tune(18, v)
+                out[f"level{l}_triple{v}_ms"] = timeit(encode, a.iters)
+        tune(T_ENCODE_ONLY_LEVEL, -1)
+        tune(18, -1)
+        del ref
+        res["encode_r05"] = out
     if "encode_sweep" in what:  # workgroups per CU for the coarse / fine segments, tiles claimed
         out = {}
         for c in (4, 6, 7):
@@ -224,9 +244,11 @@ def main():
                     tune(k, -1)
             del g
         res["scatter13_plus_ms"] = out
-    if "scatter_r05" in what:  # round 5: the coarse role's run-merged group flush (dev bit 0x20000 of tunable 10), alone and in the
-        # whole scatter, with the level threshold and the fine wave count re-swept around it; wall-clock stamps per
-        # configuration so that a clock / power log sampled beside this process can be laid over the timings
+    if "scatter_r05" in what:  # round 5: the coarse role's run-merged group flush, alone and in the whole scatter, with the level
+        # threshold and the fine wave count re-swept around it; wall-clock stamps per configuration so that a clock / power
+        # log sampled beside this process can be laid over the timings.  Dev bit 0x20000 of tunable 10 FLIPS the flush
+        # against the build's default (MI3D_RUN_MERGE: 0 when profiles/kbench_r05_scatter_run_merge.json was taken - its
+        # "run_merge" rows are the merged flush - and 1 since)
         import time
         out, stamps = {}, []
         ex = torch.randn(16, n, 2, device=dev).to(feats.dtype)
