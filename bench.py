@@ -27,7 +27,7 @@ The JSON line also carries
                  gathered, 2048 B read-modify-written by the scatter) over its launch duration measured with HIP events
                  on the launch stream during the timed steps; the other hot kernels under rooflines_other; `traffic` =
                  HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command's --profile-run
-                 (profiles/pmc_r04.json; a counter pass wraps the process from outside and costs a run of its own, so it
+                 (profiles/pmc_r05.json; a counter pass wraps the process from outside and costs a run of its own, so it
                  cannot be taken inside the timed process: `traffic_source` says which file and how it was collected);
   cpu_baseline : the reference's own pure-PyTorch renderer (nerf/renderer.py:332-479 `run` + nerf/network_tcnn.py on a
                  torch hash grid; staged sources, oracle/_ref/py) forward + backward on a bounded ray sample on this
@@ -87,7 +87,7 @@ def pmc_traffic(kernel, workload, evals):
     """(HBM bytes per launch, the file they come from) of `kernel`: the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
     scaled to this run's evaluation count; (None, None) if not collected."""
-    for name in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
+    for name in ("pmc_r05.json", "pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
             return rec["hbm_bytes_per_eval"] * evals, "profiles/" + name
@@ -337,6 +337,95 @@ def rank_views(rank, views):
     return [rank * views + v for v in range(views)], 1234 + rank
 
 
+class ClockSampler:
+    """Samples the GPU's shader clock, power and temperature on a background thread while the timed region runs (VERDICT
+    round 4, item 1d: the scatter's box-to-box spread - 32 to 42 ms on one zero census - was attributed to power
+    management without a measurement).  sysfs first (a file read per sample), `rocm-smi --json` as the fallback (a process
+    per sample, so a longer period).  Summarised into the line's `clocks`: what THIS box granted THIS run."""
+
+    def __init__(self, card_index=0, period=0.2):
+        import glob
+        self.samples, self.period, self._stop, self._thread = [], period, False, None
+        dev = None
+        for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                if card_index == 0:
+                    dev = c
+                    break
+                card_index -= 1
+        self.dev = dev
+        self.hwmon = (sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*"))) or [None])[0] if dev else None
+        self.source = "sysfs" if dev else "rocm-smi"
+        if not dev:
+            self.period = max(period, 1.0)
+
+    @staticmethod
+    def _num(text):
+        import re
+        m = re.search(r"[0-9.]+", str(text))
+        return float(m.group(0)) if m else None
+
+    def _sample(self):
+        rec = {"t": time.time()}
+        if self.dev:
+            try:
+                cur = [ln for ln in open(os.path.join(self.dev, "pp_dpm_sclk")).read().splitlines() if ln.strip().endswith("*")]
+                if cur:
+                    rec["sclk_mhz"] = self._num(cur[0].split(":", 1)[1])
+                if self.hwmon:
+                    for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6),
+                                             ("temp1_input", "temp_c", 1e-3)):
+                        f = os.path.join(self.hwmon, name)
+                        if key not in rec and os.path.exists(f):
+                            rec[key] = float(open(f).read().strip()) * scale
+            except Exception:  # noqa: BLE001
+                pass
+        if "sclk_mhz" not in rec:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"],
+                                     capture_output=True, text=True, timeout=10).stdout
+                card = next(iter(json.loads(out).values()))
+                for k, v in card.items():
+                    lk = k.lower()
+                    if "sclk" in lk and "level" not in lk:
+                        rec["sclk_mhz"] = self._num(v)
+                    elif "power" in lk and "power_w" not in rec:
+                        rec["power_w"] = self._num(v)
+                    elif "temperature" in lk and "temp_c" not in rec:
+                        rec["temp_c"] = self._num(v)
+                self.source = "rocm-smi"
+            except Exception:  # noqa: BLE001
+                pass
+        return rec
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._sample())
+                time.sleep(self.period)
+        self._stop = False
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=15)
+
+    def summary(self, t0=None, t1=None):
+        import statistics
+        s = [r for r in self.samples if (t0 is None or r["t"] >= t0) and (t1 is None or r["t"] <= t1)]
+        out = {"source": self.source, "samples": len(s), "period_s": self.period}
+        for key in ("sclk_mhz", "power_w", "temp_c"):
+            v = [r[key] for r in s if r.get(key) is not None]
+            if v:
+                out[key] = {"min": min(v), "median": statistics.median(v), "max": max(v)}
+        return out
+
+
 def gather_rank_records(rec):
     """Every rank's record on every rank (torch.distributed.all_gather_object: works on gloo and on NCCL = RCCL); a list of
     one without a process group."""
@@ -410,6 +499,8 @@ def main():
                          "NOTHING after them - no variants, no census / dense-gradient extras, no baselines - so the last "
                          "steps/steps_run_total of every kernel's dispatches in the trace ARE the timed steps "
                          "(tools/trace_sum.py --tail)")
+    ap.add_argument("--no-clock-log", action="store_true",
+                    help="do not sample the GPU's clocks / power on a background thread during the timed region")
     ap.add_argument("--refresh-every", type=int, default=16,
                     help="update_extra_state interval inside the timed loop (nerf/utils.py:970-972; 0 = never)")
     args = ap.parse_args()
@@ -551,11 +642,17 @@ def main():
         if args.profile_run:   # a marker dispatch (`spin_kernel`) either side of the timed region: tools/trace_sum.py --window
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
+        sampler = None if args.no_clock_log else ClockSampler(local_rank).start()
+        w0 = time.time()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
         local = time.perf_counter() - t0      # this rank's own clock, before it waits for the others
+        clocks = None
+        if sampler is not None:
+            sampler.stop()
+            clocks = sampler.summary(w0, time.time())
         if args.profile_run:
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
@@ -571,7 +668,7 @@ def main():
                 "scale_after": scaler.get_scale() if not render_only else None,
                 "refreshes": 0 if render_only else step.clock["refreshes"],
                 "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-                "local_ms_per_step": 1e3 * local / steps,
+                "local_ms_per_step": 1e3 * local / steps, "clocks": clocks,
                 "all_reduce_ms_per_step": sum(a.elapsed_time(b) for a, b in prof.get("all_reduce", [])) / steps}
         return elapsed, prof, info
 
@@ -753,7 +850,7 @@ def main():
             roof("grid gradient scatter: one mi3d_grid_scatter_binned_plus call = (k_bin_emit + k_bin_reduce) x slices "
                  "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
                  "GB/s", "a 'launch' here is one scatter call (kernel-trace: sum the k_bin_emit and k_bin_reduce rows of a "
-                 "step: profiles/kernel_stats_r04_bench_steps.csv, collected on THIS command's own timed steps with "
+                 "step: profiles/kernel_stats_r05_bench_steps.csv, collected on THIS command's own timed steps with "
                  "--profile-run); algorithmic bytes = 2048 B per evaluation read-modify-write of the table, counted ONLY for "
                  "the (evaluation, level) gradient pairs that are not exactly zero (grad_nonzero_pair_fraction: binary16 "
                  "gradients underflow, and adding a zero is what the reference's atomics would do); dense-gradient figures: "
@@ -807,6 +904,8 @@ def main():
             # exclusive phases of the step (HIP events on the launch stream): their sum is the step
             "phases_ms_per_step": {k[6:]: sum(v) / args.steps for k, v in ms.items() if k.startswith("phase:")},
             "peak_mem_GiB": info["peak_mem_GiB"],
+            # shader clock / board power / temperature sampled on a background thread during the timed region (ClockSampler)
+            "clocks": info.get("clocks"),
         }
         line["phases_ms_per_step"]["unattributed"] = line["ms_per_step"] - sum(line["phases_ms_per_step"].values())
         if census is not None:
