@@ -340,24 +340,33 @@ def rank_views(rank, views):
 class ClockSampler:
     """Samples the GPU's shader clock, power and temperature on a background thread while the timed region runs (VERDICT
     round 4, item 1d: the scatter's box-to-box spread - 32 to 42 ms on one zero census - was attributed to power
-    management without a measurement).  sysfs first (a file read per sample), `rocm-smi --json` as the fallback (a process
-    per sample, so a longer period).  Summarised into the line's `clocks`: what THIS box granted THIS run."""
+    management without a measurement).  sysfs only (a few small file reads per sample, no child process): the card is the
+    one whose PCI address torch reports for the device; without such a card nothing is sampled.  Summarised into the
+    line's `clocks`: what THIS box granted THIS run."""
 
-    def __init__(self, card_index=0, period=0.2):
+    def __init__(self, pci_address=None, period=0.25):
         import glob
         self.samples, self.period, self._stop, self._thread = [], period, False, None
         dev = None
-        for c in sorted(glob.glob("/sys/class/drm/card*/device")):
-            if os.path.exists(os.path.join(c, "pp_dpm_sclk")):
-                if card_index == 0:
+        if pci_address:
+            for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.basename(os.path.realpath(c)).lower() == pci_address.lower() and \
+                        os.path.exists(os.path.join(c, "pp_dpm_sclk")):
                     dev = c
                     break
-                card_index -= 1
         self.dev = dev
         self.hwmon = (sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*"))) or [None])[0] if dev else None
-        self.source = "sysfs" if dev else "rocm-smi"
-        if not dev:
-            self.period = max(period, 1.0)
+        self.source = f"sysfs {pci_address}" if dev else None
+
+    @staticmethod
+    def pci_address_of(torch_device):
+        """'dddd:bb:dd.0' of a torch CUDA / HIP device, or None if this torch build does not expose it."""
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_device)
+            return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            return None
 
     @staticmethod
     def _num(text):
@@ -367,39 +376,24 @@ class ClockSampler:
 
     def _sample(self):
         rec = {"t": time.time()}
-        if self.dev:
-            try:
-                cur = [ln for ln in open(os.path.join(self.dev, "pp_dpm_sclk")).read().splitlines() if ln.strip().endswith("*")]
-                if cur:
-                    rec["sclk_mhz"] = self._num(cur[0].split(":", 1)[1])
-                if self.hwmon:
-                    for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6),
-                                             ("temp1_input", "temp_c", 1e-3)):
-                        f = os.path.join(self.hwmon, name)
-                        if key not in rec and os.path.exists(f):
-                            rec[key] = float(open(f).read().strip()) * scale
-            except Exception:  # noqa: BLE001
-                pass
-        if "sclk_mhz" not in rec:
-            try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"],
-                                     capture_output=True, text=True, timeout=10).stdout
-                card = next(iter(json.loads(out).values()))
-                for k, v in card.items():
-                    lk = k.lower()
-                    if "sclk" in lk and "level" not in lk:
-                        rec["sclk_mhz"] = self._num(v)
-                    elif "power" in lk and "power_w" not in rec:
-                        rec["power_w"] = self._num(v)
-                    elif "temperature" in lk and "temp_c" not in rec:
-                        rec["temp_c"] = self._num(v)
-                self.source = "rocm-smi"
-            except Exception:  # noqa: BLE001
-                pass
+        try:
+            cur = [ln for ln in open(os.path.join(self.dev, "pp_dpm_sclk")).read().splitlines() if ln.strip().endswith("*")]
+            if cur:
+                rec["sclk_mhz"] = self._num(cur[0].split(":", 1)[1])
+            if self.hwmon:
+                for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6),
+                                         ("temp1_input", "temp_c", 1e-3)):
+                    f = os.path.join(self.hwmon, name)
+                    if key not in rec and os.path.exists(f):
+                        rec[key] = float(open(f).read().strip()) * scale
+        except Exception:  # noqa: BLE001
+            pass
         return rec
 
     def start(self):
         import threading
+        if self.dev is None:
+            return self
 
         def loop():
             while not self._stop:
@@ -413,10 +407,12 @@ class ClockSampler:
     def stop(self):
         self._stop = True
         if self._thread is not None:
-            self._thread.join(timeout=15)
+            self._thread.join(timeout=5)
 
     def summary(self, t0=None, t1=None):
         import statistics
+        if self.dev is None:
+            return None
         s = [r for r in self.samples if (t0 is None or r["t"] >= t0) and (t1 is None or r["t"] <= t1)]
         out = {"source": self.source, "samples": len(s), "period_s": self.period}
         for key in ("sclk_mhz", "power_w", "temp_c"):
@@ -642,23 +638,24 @@ def main():
         if args.profile_run:   # a marker dispatch (`spin_kernel`) either side of the timed region: tools/trace_sum.py --window
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
-        sampler = None if args.no_clock_log else ClockSampler(local_rank).start()
+        sampler = None if args.no_clock_log else ClockSampler(ClockSampler.pci_address_of(dev)).start()
         w0 = time.time()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
         local = time.perf_counter() - t0      # this rank's own clock, before it waits for the others
-        clocks = None
-        if sampler is not None:
-            sampler.stop()
-            clocks = sampler.summary(w0, time.time())
+        w1 = time.time()
         if args.profile_run:
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        clocks = None
+        if sampler is not None:   # (after the clock has stopped: joining the sampler's thread may take a period)
+            sampler.stop()
+            clocks = sampler.summary(w0, w1)
         prof, grid_ops.PROFILE = grid_ops.PROFILE, None
         if dist.is_initialized():
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

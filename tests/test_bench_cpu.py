@@ -35,3 +35,20 @@ def test_gpus_n_becomes_the_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and os.path.samefile(cmd[-5], BENCH)
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_clock_sampler_without_a_card_samples_nothing():
+    """bench.ClockSampler reads sysfs of the card whose PCI address torch reports; with no such card (this container) it
+    starts no thread and reports None - it never falls back to forking a child from the benchmark process."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    bench = importlib.import_module("bench")
+    assert bench.ClockSampler.pci_address_of(torch.device("cpu")) is None
+    c = bench.ClockSampler(None).start()
+    assert c._thread is None
+    c.stop()
+    assert c.summary() is None
+    c = bench.ClockSampler("0000:ff:1f.0").start()      # an address no card has
+    c.stop()
+    assert c.summary() is None
