@@ -1115,6 +1115,12 @@ constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFF
 // the coarse role alone 36.3 -> 34.2 / 25.9 -> 24.2 (profiles/kbench_r05_scatter_run_merge.json)
 #define MI3D_RUN_MERGE 1
 #endif
+#ifndef MI3D_MASK_FMA
+// the coarse role's register sums by fused multiply-add with a 0 / 1 lane mask instead of select + add (the emit is bound by
+// vector-instruction issue).  Round 5, one box, three interleaved pairs (profiles/kbench_r05_scatter_mask_fma.json): real
+// census 36.55-37.09 -> 36.34-36.60 ms, dense 53.70-54.16 -> 53.46-53.52; same gradient to 8e-8 / 1.1e-7 x max
+#define MI3D_MASK_FMA 1
+#endif
 // Fine levels: the x-pair records of kChunkPts stencil points of a tile (64 lanes x 4 pairs each) are SORTED BY BIN in the
 // wave's LDS before they leave, so that what goes to a region is a contiguous run of records (consecutive lanes store
 // consecutive 16-byte slots) instead of one scattered 16-byte store per lane.  The staging area is the memory the coarse
@@ -1169,9 +1175,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                  // 0x20000 toggles the run-merged group flush against its product default
     const bool face_on = !(fine_level_major & 0x10000u);
     const bool run_merge = ((fine_level_major & 0x20000u) != 0u) != (MI3D_RUN_MERGE != 0);
+    const bool mask_fma = ((fine_level_major & 0x40000u) != 0u) != (MI3D_MASK_FMA != 0);   // 0x40000 flips the masked fma
 #else
     constexpr bool face_on = true;
     constexpr bool run_merge = MI3D_RUN_MERGE != 0;
+    constexpr bool mask_fma = MI3D_MASK_FMA != 0;
 #endif
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
@@ -1357,10 +1365,19 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
             auto face_pass = [&](auto axis_tag, bool fa, bool fb, const float (&a0)[8], const float (&a1)[8],
                                  const float (&b0)[8], const float (&b1)[8]) __attribute__((always_inline)) {
                 constexpr uint32_t AXIS = decltype(axis_tag)::value, m = 1u << AXIS;
+                if (mask_fma) {
+                    const float mfa = fa ? 1.0f : 0.0f, mfb = fb ? 1.0f : 0.0f;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) {
+                        if (!(k & m)) { acc0[k | m] = fmaf(a0[k], mfa, acc0[k | m]); acc1[k | m] = fmaf(a1[k], mfa, acc1[k | m]); }
+                        else { acc0[k & ~m] = fmaf(b0[k], mfb, acc0[k & ~m]); acc1[k & ~m] = fmaf(b1[k], mfb, acc1[k & ~m]); }
+                    }
+                } else {
 #pragma unroll
                 for (uint32_t k = 0; k < 8; ++k) {
                     if (!(k & m)) { acc0[k | m] += fa ? a0[k] : 0.f; acc1[k | m] += fa ? a1[k] : 0.f; }   // +: its near face
                     else { acc0[k & ~m] += fb ? b0[k] : 0.f; acc1[k & ~m] += fb ? b1[k] : 0.f; }          // -: its near face
+                }
                 }
                 uint32_t e[4];
                 float f0[4], f1[4];
@@ -1407,8 +1424,14 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                                 u1[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc1[k]), CTRL, 0xf, 0xf, true));
                             }
                             const bool take = pos >= off;
+                            if (mask_fma) {
+                                const float mt = take ? 1.0f : 0.0f;
+#pragma unroll
+                                for (uint32_t k = 0; k < 8; ++k) { acc0[k] = fmaf(u0[k], mt, acc0[k]); acc1[k] = fmaf(u1[k], mt, acc1[k]); }
+                            } else {
 #pragma unroll
                             for (uint32_t k = 0; k < 8; ++k) { acc0[k] += take ? u0[k] : 0.f; acc1[k] += take ? u1[k] : 0.f; }
+                            }
                         };
                         seg_step(std::integral_constant<int, 0x111>{}, 1u);   // row_shr:1
                         seg_step(std::integral_constant<int, 0x112>{}, 2u);   // row_shr:2
@@ -1718,10 +1741,24 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     }
                     if (__ballot(same_a || same_b) != 0ull) {
                         acc_any = true;
+                        if (mask_fma) {
+                            // (one fused multiply-add per value by a 0 / 1 lane mask instead of select + add: the emit is
+                            // bound by vector-instruction issue, DESIGN.md 3.2''; every value here is finite - a tile with a
+                            // non-finite gradient took the `dead` route - so x * 0 is 0)
+                            const float ma = same_a ? 1.0f : 0.0f;
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) { acc0[k] = fmaf(a0[k], ma, acc0[k]); acc1[k] = fmaf(a1[k], ma, acc1[k]); }
+                            if (paired) {
+                                const float mb = same_b ? 1.0f : 0.0f;
+#pragma unroll
+                                for (uint32_t k = 0; k < 8; ++k) { acc0[k] = fmaf(b0[k], mb, acc0[k]); acc1[k] = fmaf(b1[k], mb, acc1[k]); }
+                            }
+                        } else {
 #pragma unroll
                         for (uint32_t k = 0; k < 8; ++k) {
                             acc0[k] += (same_a ? a0[k] : 0.f) + (same_b ? b0[k] : 0.f);
                             acc1[k] += (same_a ? a1[k] : 0.f) + (same_b ? b1[k] : 0.f);
+                        }
                         }
                     }
                     bool ex_a = has_a && !same_a, ex_b = has_b && !same_b;
@@ -1915,16 +1952,18 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                         uint32_t l0, t;
                         float w, fx, dx, dy;
                         unpack_row12(rec[u].w0, rec[u].w1, rec[u].w2, l0, t, w, fx, dx, dy);
-                        const float a = w * dx, bb = w * dy, gx = 1.0f - fx;
-                        atomicAdd(&acc[l0], fixed_point((gx * a) * scale));
-                        atomicAdd(&acc[kBinEntries + l0], fixed_point((gx * bb) * scale));
+                        // (the level's power-of-two scale goes into the weight once - an exact scaling, it commutes with
+                        // every rounding below - instead of into each of the four products)
+                        const float ws = w * scale, a = ws * dx, bb = ws * dy, gx = 1.0f - fx;
+                        atomicAdd(&acc[l0], fixed_point(gx * a));
+                        atomicAdd(&acc[kBinEntries + l0], fixed_point(gx * bb));
                         if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
                             // (the flip is masked with the level's size first, as the emit and the 16-byte branch do: a
                             // table smaller than a bin - log2_hashmap_size < 13 - must not see carry bits beyond it)
                             const uint32_t l1 = hashed ? (l0 ^ (((1u << t) - 1u) & (T.level[lvl].size - 1u))) & (kBinEntries - 1u)
                                                        : l0 + 1u;
-                            atomicAdd(&acc[l1], fixed_point((fx * a) * scale));
-                            atomicAdd(&acc[kBinEntries + l1], fixed_point((fx * bb) * scale));
+                            atomicAdd(&acc[l1], fixed_point(fx * a));
+                            atomicAdd(&acc[kBinEntries + l1], fixed_point(fx * bb));
                         }
                     }
                 }

@@ -258,7 +258,11 @@ def main():
             g = gradient_planes(feats.dtype)
             tag = "real_" if census else "dense_"
             ref = None
+            MF = 0x40000   # flips the masked fused multiply-add of the coarse role's register sums (MI3D_MASK_FMA)
             for name, kvs in (("base", {}), ("run_merge", {10: RM}), ("base_2", {}), ("run_merge_2", {10: RM}),
+                              ("mask_fma", {10: MF}), ("base_2b", {}), ("mask_fma_2", {10: MF}), ("base_2c", {}),
+                              ("mask_fma_3", {10: MF}),
+                              ("coarse_only_mask_fma", {5: 0x007F, 10: MF}),
                               ("coarse_only_base", {5: 0x007F}), ("coarse_only_run_merge", {5: 0x007F, 10: RM}),
                               ("fine_only", {5: 0xFF80}),
                               ("run_merge_merge30", {10: RM, 15: 30}), ("run_merge_merge58", {10: RM, 15: 58}),
@@ -270,12 +274,12 @@ def main():
                 out[tag + name] = timeit(lambda: field_ops.scatter_binned(
                     xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex), a.iters)
                 stamps.append((tag + name, t0, time.time()))
-                if name in ("base", "run_merge"):   # same gradient, up to the fp32 rounding of a segment's register sum
+                if name in ("base", "run_merge", "mask_fma"):   # same gradient, up to the fp32 rounding of the register sums
                     got = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex)
                     if ref is None:
                         ref = got
                     else:
-                        out[tag + "run_merge_max_err_rel"] = float((got - ref).abs().max() / ref.abs().max())
+                        out[tag + name + "_max_err_rel"] = float((got - ref).abs().max() / ref.abs().max())
                     del got
                 for k in kvs:
                     tune(k, -1)
