@@ -1115,10 +1115,21 @@ constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFF
 // the coarse role alone 36.3 -> 34.2 / 25.9 -> 24.2 (profiles/kbench_r05_scatter_run_merge.json)
 #define MI3D_RUN_MERGE 1
 #endif
+#ifndef MI3D_DYN_IDX
+// a tile's 13 gradient pairs wait in registers; the point loops pick theirs by a UNIFORM index.  Written as select chains
+// (round 3: "picked by a select chain (p is uniform)") that is 12 v_cndmask per pick, and hipcc kept part of the array in
+// scratch memory on top (96 bytes of private segment); indexed directly, hipcc uses gfx9's relative register addressing
+// (s_set_gpr_idx_on + one move) and the scratch array goes (28 bytes).  Product-grade builds in ONE process
+// (tools/scatter_ab_libs.py, profiles/scatter_ab_libs_r05.json), three interleaved rounds: dense gradients 52.56-52.69 ->
+// 50.74-50.78 ms, real census 43.01-43.03 -> 40.67-40.77; same gradient (1.7e-8 x max: the order of the float atomics).
+#define MI3D_DYN_IDX 1
+#endif
 #ifndef MI3D_MASK_FMA
-// the coarse role's register sums by fused multiply-add with a 0 / 1 lane mask instead of select + add (the emit is bound by
-// vector-instruction issue).  Round 5, one box, three interleaved pairs (profiles/kbench_r05_scatter_mask_fma.json): real
-// census 36.55-37.09 -> 36.34-36.60 ms, dense 53.70-54.16 -> 53.46-53.52; same gradient to 8e-8 / 1.1e-7 x max
+// the coarse role's register sums by fused multiply-add with a 0 / 1 lane mask instead of select + add.  Round 5: in the
+// tools build (both forms behind a run-time switch, profiles/kbench_r05_scatter_mask_fma.json) real census 36.55-37.09 ->
+// 36.34-36.60 ms, dense 53.70-54.16 -> 53.46-53.52; between two PRODUCT-grade builds in one process
+// (profiles/scatter_ab_libs_r05.json) no difference (43.02 vs 43.05, 52.62 vs 52.65): neutral, kept; same gradient to
+// 1e-7 x max
 #define MI3D_MASK_FMA 1
 #endif
 // Fine levels: the x-pair records of kChunkPts stencil points of a tile (64 lanes x 4 pairs each) are SORTED BY BIN in the
@@ -1176,10 +1187,12 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     const bool face_on = !(fine_level_major & 0x10000u);
     const bool run_merge = ((fine_level_major & 0x20000u) != 0u) != (MI3D_RUN_MERGE != 0);
     const bool mask_fma = ((fine_level_major & 0x40000u) != 0u) != (MI3D_MASK_FMA != 0);   // 0x40000 flips the masked fma
+    const bool dyn_idx = ((fine_level_major & 0x80000u) != 0u) != (MI3D_DYN_IDX != 0);     // 0x80000 flips the register indexing
 #else
     constexpr bool face_on = true;
     constexpr bool run_merge = MI3D_RUN_MERGE != 0;
     constexpr bool mask_fma = MI3D_MASK_FMA != 0;
+    constexpr bool dyn_idx = MI3D_DYN_IDX != 0;
 #endif
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
@@ -1508,11 +1521,16 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     uint32_t craw0[kChunkPts], craw1[kChunkPts];
                     static_assert(kChunkPts == 2, "the pick below walks the points two at a time");
                     craw0[0] = raw0[0]; craw0[1] = raw0[1]; craw1[0] = raw1[0]; craw1[1] = raw1[HP ? 0 : 1];
+                    if (dyn_idx) {
+                        const uint32_t ka = p0 < (uint32_t)kMaxPts ? p0 : 0u, kb = ka + 1 < (uint32_t)kMaxPts ? ka + 1 : ka;
+                        craw0[0] = raw0[ka]; craw0[1] = raw0[kb]; craw1[0] = raw1[HP ? 0 : ka]; craw1[1] = raw1[HP ? 0 : kb];
+                    } else {
 #pragma unroll
                     for (uint32_t k = 2; k < (uint32_t)kMaxPts; k += 2) {
                         const uint32_t k1 = k + 1 < (uint32_t)kMaxPts ? k + 1 : k;
                         craw0[0] = (p0 == k) ? raw0[k] : craw0[0]; craw0[1] = (p0 == k) ? raw0[k1] : craw0[1];
                         craw1[0] = (p0 == k) ? raw1[HP ? 0 : k] : craw1[0]; craw1[1] = (p0 == k) ? raw1[HP ? 0 : k1] : craw1[1];
+                    }
                     }
                     // pass 1: cells, entries, and how many records each bin gets
 #pragma unroll
@@ -1690,8 +1708,13 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                 auto eval_point = [&](uint32_t p, uint32_t &cx, uint32_t &cy, uint32_t &cz, float (&v0)[8], float (&v1)[8])
                     __attribute__((always_inline)) {
                     uint32_t r0 = raw0[0], r1 = raw1[0];
+                    if (dyn_idx) {   // (p is uniform: one relative register move instead of a 12-step select chain)
+                        const uint32_t pc = p < (uint32_t)kMaxPts ? p : 0u;
+                        r0 = raw0[pc]; r1 = raw1[HP ? 0 : pc];
+                    } else {
 #pragma unroll
                     for (uint32_t k = 1; k < (uint32_t)kMaxPts; ++k) { r0 = (p == k) ? raw0[k] : r0; r1 = (p == k) ? raw1[HP ? 0 : k] : r1; }
+                    }
                     float2 d = HP
                         ? make_float2((float)__builtin_bit_cast(_Float16, (unsigned short)(r0 & 0xFFFFu)),
                                       (float)__builtin_bit_cast(_Float16, (unsigned short)(r0 >> 16)))

@@ -263,6 +263,8 @@ def main():
                               ("mask_fma", {10: MF}), ("base_2b", {}), ("mask_fma_2", {10: MF}), ("base_2c", {}),
                               ("mask_fma_3", {10: MF}),
                               ("coarse_only_mask_fma", {5: 0x007F, 10: MF}),
+                              ("dyn_idx", {10: 0x80000}), ("base_2d", {}), ("dyn_idx_2", {10: 0x80000}), ("base_2e", {}),
+                              ("dyn_idx_3", {10: 0x80000}),
                               ("coarse_only_base", {5: 0x007F}), ("coarse_only_run_merge", {5: 0x007F, 10: RM}),
                               ("fine_only", {5: 0xFF80}),
                               ("run_merge_merge30", {10: RM, 15: 30}), ("run_merge_merge58", {10: RM, 15: 58}),
@@ -274,7 +276,7 @@ def main():
                 out[tag + name] = timeit(lambda: field_ops.scatter_binned(
                     xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex), a.iters)
                 stamps.append((tag + name, t0, time.time()))
-                if name in ("base", "run_merge", "mask_fma"):   # same gradient, up to the fp32 rounding of the register sums
+                if name in ("base", "run_merge", "mask_fma", "dyn_idx"):   # same gradient, up to the fp32 rounding of the register sums
                     got = field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g, cfg, 2 * 3 ** 0.5 / 1024, 12196240, extra0=ex)
                     if ref is None:
                         ref = got
