@@ -1953,7 +1953,14 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 
     bool any = false;
 #ifndef MI3D_REDUCE_U
-#define MI3D_REDUCE_U 8
+// records in flight per lane.  Round 4 swept 4 / 8 / 16 and found no difference - there was none to find: the loads were
+// predicated (`i < cnt ? src[i] : 0`), hipcc waited for each on the spot (eight `global_load_dwordx3` + `s_waitcnt vmcnt(0)`
+// pairs in a row), nothing was ever in flight.  With unconditional loads from a clamped index they are issued back to
+// back (round 5, read off the ISA).  Product-grade builds in one process (tools/scatter_ab_libs.py,
+// profiles/scatter_ab_libs_r05_reduce.json): predicated 8: dense 51.13 / real 40.03 ms; in flight 8: 50.67 / 40.07; in
+// flight 16: 51.6 / 41.1; in flight 4: **50.25 / 39.8** - the reduce is bound by its LDS atomics, not by the latency of
+// its loads (16 waves per CU hid that already): a small gain, and the short batch wins.
+#define MI3D_REDUCE_U 4
 #endif
     constexpr uint32_t U = MI3D_REDUCE_U;  // records in flight per lane
     for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
@@ -1966,8 +1973,11 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
                 Row12 rec[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
+                    // (unconditional, from a clamped index: a predicated load makes hipcc wait for it on the spot - the eight
+                    // records "in flight" were eight HBM round trips in a row, each behind its own s_waitcnt vmcnt(0), until
+                    // round 5 read the ISA; what a lane beyond cnt fetched is never looked at)
                     const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = i < cnt ? src[i] : Row12{0u, 0u, 0u};
+                    rec[u] = src[i < cnt ? i : cnt - 1u];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
@@ -1999,7 +2009,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
                     const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = i < cnt ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+                    rec[u] = src[i < cnt ? i : cnt - 1u];   // (unconditional: see the 12-byte branch)
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
@@ -2027,7 +2037,7 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
                     const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = i < cnt ? src[i] : BinRecord{0u, 0.f, 0.f};
+                    rec[u] = src[i < cnt ? i : cnt - 1u];   // (unconditional: see the 12-byte branch)
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
