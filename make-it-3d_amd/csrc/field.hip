@@ -45,6 +45,14 @@
 // TIMING ONLY (variant builds for tools/mlp_ab.py --timing-only; the gradients are wrong with either bit): what a group of
 // the backward's vector instructions costs - 1 = no bias-gradient sums (40 dot products per tile), 2 = no ReLU masks on
 // the gradients (64 packed operations per tile)
+#ifndef MI3D_MLP_DO_LDS
+// the 4-wide output gradient's tile turned round through the wave's LDS like every other binary16 tile, instead of on the
+// matrix core (VERDICT r04 item 3 / DESIGN.md 7.3a): 42 MFMAs and 72 packed converts per tile instead of 43 / 80.  Both
+// builds in one process (tools/mlp_ab.py, profiles/mlp_ab_r05_do_lds.json): every template instance's input-gradient
+// planes bit-identical, weight gradients to 1.5e-6 (the order of their float atomics); 13 points 8.37 -> 8.34 ms, point-0
+// pass 0.71 -> 0.71: the last matrix-core transpose of the binary16 kernels is gone, the time it took was already hidden.
+#define MI3D_MLP_DO_LDS 1
+#endif
 #ifndef MI3D_MLP_BWD_TIMING_CUT
 #define MI3D_MLP_BWD_TIMING_CUT 0
 #endif
@@ -1173,9 +1181,14 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
             dHL[t] = (MI3D_MLP_BWD_TIMING_CUT & 2) ? P::cast(acc) : P::masked(acc, HL[t]);
         }
         {
-            f32x16 tO = splat(0.f);
-            P::mma_lo(tO, dO, blk_fresh(B::IDX));
-            const KB dOp = P::cast(tO);  // lane = output index, values = the tile's samples
+            KB dOp;   // lane = output index, values = the tile's samples
+            if constexpr (P::kLdsTranspose && MI3D_MLP_DO_LDS != 0) {
+                dOp = transpose(dO, B::IDX);   // (kind X over the 4 outputs: through the wave's LDS like every other tile)
+            } else {
+                f32x16 tO = splat(0.f);
+                P::mma_lo(tO, dO, blk_fresh(B::IDX));
+                dOp = P::cast(tO);
+            }
             if (!(MI3D_MLP_BWD_TIMING_CUT & 1)) gb3 += P::sum(dOp);
 #pragma unroll
             for (int t = 0; t < NTH; ++t) {
