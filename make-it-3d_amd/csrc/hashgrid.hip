@@ -926,6 +926,13 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 // forward left behind - rides along (mi3d_grid_scatter_binned_plus); the coarse role sends a +-eps neighbour that left the
 // base cell through a shared-face pass (face_pass: the near face into the register sums, the four far corners through the
 // gather table); level 7 (cells of 3.9 marching steps at C2) is a record level now (merge_steps).
+// Round 5 (DESIGN.md 3.2''): the emit turned out to be bound by vector-instruction issue (0.71 of its SIMDs' slots at three
+// waves per SIMD), so what moved it was its instruction stream: the coarse role sums a run's lanes in registers before its
+// gather-table flush (MI3D_RUN_MERGE), a tile's gradient pairs are picked by relative register indexing instead of select
+// chains that hipcc had half-spilled to scratch (MI3D_DYN_IDX), and the reduce's record loads are unconditional, so that
+// they really are in flight (MI3D_REDUCE_U).  Variants are judged between PRODUCT-grade builds loaded into one process
+// (tools/scatter_ab_libs.py): the tools build, with every variant behind a run-time switch, allocates registers for all
+// of them.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
 constexpr uint32_t kEmitWavesMax = 1536;
 constexpr uint32_t kReduceWavesC = 16;  // waves of a reduce workgroup (= kReduceWaves below)
