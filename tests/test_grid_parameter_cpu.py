@@ -91,3 +91,19 @@ def test_deferral_is_off_for_parameters_with_post_accumulate_grad_hooks():
     assert grid_ops.DEFER_POINT0
     p.register_post_accumulate_grad_hook(lambda t: None)
     assert field_ops._may_defer(p, 13, 1) is False
+
+
+def test_eval_round_budget_and_schedule_defaults():
+    """mi3d.renderer's compact eval rounds (DESIGN.md 3.5'): the row budget a round gets - 16 rows per ray, at least 2^18,
+    at most max(2^21, 2 N) - and the attributes a user may set."""
+    import types
+    from mi3d.renderer import NeRFRenderer
+    opt = types.SimpleNamespace(bound=1.0, cuda_ray=False, min_near=0.1, density_thresh=10.0, bg_radius=-1)
+    r = NeRFRenderer(opt)
+    assert r.infer_schedule == "budget" and r.infer_budget_rounds % 2 == 0 and r.infer_graph_rounds % 2 == 0
+    assert [r.budget_rows(n) for n in (1024, 128 * 128, 256 * 256, 512 * 512, 1024 * 1024, 2048 * 2048)] == \
+        [1 << 18, 1 << 18, 1 << 20, 1 << 21, 1 << 21, 2 * 2048 * 2048]
+    r.infer_budget_rows = 5000
+    assert r.budget_rows(128 * 128) == 5000
+    r.infer_budget_rows = 0
+    assert r.budget_rows(7) == 1
