@@ -142,7 +142,7 @@ def cpu_baseline_c1():
         out = forward()
         ((out["image"] ** 2).mean() + out["loss_orient"]).backward()
 
-    def timed(fn, warm=3, n=10, budget=45.0):
+    def timed(fn, warm=3, n=10, budget=25.0):
         t_start = time.perf_counter()
         for _ in range(warm):
             fn()
@@ -167,7 +167,7 @@ def cpu_baseline_c1():
             "forward_backward_rays_per_s": N / tb, "forward_backward_samples_per_s": m / tb}
 
 
-def cpu_baseline_reference(wl, budget_s=60.0, min_rays=256):
+def cpu_baseline_reference(wl, budget_s=25.0, min_rays=128):
     """Labelled extra: the headline workload's own shape (max_steps uniform samples per ray, 13 field evaluations per
     sample with the smoothness term, L=16 + 3x64) through the reference's NeRFRenderer.run + NeRFNetwork on a torch
     hash grid, forward + backward, on >= 256 rays of the same view, extrapolated to the full view."""
@@ -316,16 +316,43 @@ def _cpu_leg(kind, workload, hard_limit_s):
     return None
 
 
-def cpu_baseline(workload):
-    """Child processes with hard wall-clock limits (the legs must never hold the bench line hostage).  Primary:
-    BASELINE config 1 whole through the reference's own renderer; extra: the headline workload's
-    shape on >= 256 rays, extrapolated; the C oracle port only when the staged reference sources are absent."""
-    res = _cpu_leg("c1", workload, 150)
-    extra = _cpu_leg("reference", workload, 150) if WORKLOADS[workload].get("mode") is None else None
-    if res is None:
-        res = extra or _cpu_leg("port", workload, 150) or {"value": None, "error": "every CPU baseline leg failed"}
-    elif extra is not None:
-        res["headline_shape_extrapolated"] = extra
+CPU_LEG_LIMIT_S = 90   # hard wall-clock limit of the CPU child (both legs: ~25 s + ~20 s of CPU work + one torch import)
+
+
+def cpu_baseline_start(workload):
+    """ONE child process with a hard wall-clock limit (the legs must never hold the bench line hostage), started before
+    this process builds its model and collected before the headline's warm-up (see main).  Primary: BASELINE config 1 whole through the reference's own renderer (BASELINE.md section 2);
+    extra: the headline workload's shape on a bounded ray sample, extrapolated."""
+    kind = "both" if WORKLOADS[workload].get("mode") is None else "c1"
+    try:
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload", workload],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), time.perf_counter()
+    except Exception as e:  # noqa: BLE001
+        log(f"cpu baseline child did not start: {e!r}")
+        return None, time.perf_counter()
+
+
+def cpu_baseline_collect(started, workload):
+    """The child's result; the C oracle port (its own short child) only when the reference legs produced nothing."""
+    child, t0 = started
+    res = None
+    if child is not None:
+        try:
+            out, err = child.communicate(timeout=max(5.0, CPU_LEG_LIMIT_S - (time.perf_counter() - t0)))
+            for ln in reversed(out.strip().splitlines()):
+                if ln.startswith("{"):
+                    res = json.loads(ln)
+                    break
+            if res is None:
+                log(f"cpu baseline child printed no result: {err[-300:]}")
+        except subprocess.TimeoutExpired:
+            child.kill()
+            child.communicate()
+            log(f"cpu baseline child exceeded {CPU_LEG_LIMIT_S} s")
+        except Exception as e:  # noqa: BLE001
+            log(f"cpu baseline child failed: {e!r}")
+    if res is None or res.get("value") is None:
+        res = _cpu_leg("port", workload, 60) or {"value": None, "error": "every CPU baseline leg failed"}
     return res
 
 
@@ -489,7 +516,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (under torch.distributed.run): the "
                          "gradient all-reduce, the state broadcast and the occupancy broadcast then really execute")
-    ap.add_argument("--cpu-baseline-only", default=None, choices=["c1", "reference", "port"], help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-only", default=None, choices=["c1", "reference", "both", "port"], help=argparse.SUPPRESS)
+    ap.add_argument("--reference-shaped-only", action="store_true",
+                    help="time ONLY the reference-shaped leg (the reference's NeRFNetwork / run_cuda Python on the drop-in "
+                         "packages) - the command a rocprofv3 --kernel-trace of that route wraps")
+    ap.add_argument("--all-variants", action="store_true",
+                    help="also time the t=300 branch with the CLIP weights left trainable (the reference's wasted backward "
+                         "into the towers) at the full --variant-steps; the default run gives it 2 steps")
     ap.add_argument("--profile-run", action="store_true",
                     help="the run rocprofv3 wraps (profiles/README.md): the headline's settle + warm-up + timed steps and "
                          "NOTHING after them - no variants, no census / dense-gradient extras, no baselines - so the last "
@@ -505,11 +538,21 @@ def main():
 
     if args.cpu_baseline_only:   # child process of cpu_baseline(): host cores only, no GPU
         wl = WORKLOADS[args.workload]
-        if args.cpu_baseline_only in ("c1", "reference"):
+        if args.cpu_baseline_only in ("c1", "reference", "both"):
             from oracle import ref_import
             if not ref_import.available():
                 raise SystemExit("reference sources not staged")
-            print(json.dumps(cpu_baseline_c1() if args.cpu_baseline_only == "c1" else cpu_baseline_reference(wl)))
+            if args.cpu_baseline_only == "reference":
+                res = cpu_baseline_reference(wl)
+            else:
+                res = cpu_baseline_c1()
+                print(json.dumps(res), flush=True)   # (the primary leg is on record even if the extra is cut off)
+                if args.cpu_baseline_only == "both":
+                    try:
+                        res["headline_shape_extrapolated"] = cpu_baseline_reference(wl)
+                    except Exception as e:  # noqa: BLE001
+                        res["headline_shape_extrapolated"] = {"value": None, "error": repr(e)}
+            print(json.dumps(res))
         else:
             print(json.dumps(cpu_baseline_port(wl)))
         return
@@ -522,6 +565,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench invalid: --gpus {args.gpus} but WORLD_SIZE is {world}")
     ensure_built()
+    # The CPU baseline works on host cores in ONE child process while this process builds the model, lets MIOpen pick its
+    # kernels and settles the loss scale (all untimed); the headline's warm-up does not start before the child is done, so
+    # no timed figure - headline, variants, reference-shaped leg - shares the host with it.  (Round 5 ran two children at
+    # the END of the run, one after the other: 198 s of a 454 s driver run.  Round 6's first try ran the child beside
+    # the variants: a 32-thread host job next to the eager VAE's ~900 launches per step inflated them by 10-40 %.)
+    cpu_child = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.reference_shaped_only:
+        cpu_child = cpu_baseline_start(args.workload)
 
     import torch
     import torch.distributed as dist
@@ -562,6 +613,15 @@ def main():
     render_only = wl.get("mode") == "render"
     if render_only:
         opt.lambda_smooth = 0.0
+
+    if args.reference_shaped_only:   # the command `rocprofv3 --kernel-trace` wraps for that route (profiles/README.md)
+        # (at loss scale 2.0: where the headline's scaler settles on this workload - the reference's 65536 would spend the
+        # leg on overflowing steps)
+        res = reference_shaped(model, guidance, text_z, opt, view_rays[0], wl, t_fixed, dev, 2.0, steps=max(1, args.steps),
+                               mark=True)
+        if rank == 0:
+            print(json.dumps(res))
+        return
 
     def make_step(the_model, the_optimizer, the_scaler, schedule, sync):
         def render_step():
@@ -673,11 +733,17 @@ def main():
     # settle the loss scale (untimed; before the W warm-up steps of the contract)
     settle = make_step(model, optimizer, scaler, HEADLINE[1], grad_sync)
     good, tries = 0, 0
+    settle_s = []
     while not render_only and opt.fp16 and good < 4 and tries < 60:
         before = scaler.get_scale()
+        t_s = time.perf_counter()
         settle()
-        good = good + 1 if scaler.get_scale() >= before else 0
+        good = good + 1 if scaler.get_scale() >= before else 0   # (get_scale() synchronises: the step has finished)
+        settle_s.append(round(time.perf_counter() - t_s, 2))
         tries += 1
+    if settle_s:
+        log(f"settle steps took {settle_s} s (the first carries MIOpen's kernel selection and the U-Net graph capture; an "
+            f"overflowing step hands its inf / NaN gradients to float atomics, as the reference does)")
     if not render_only and opt.fp16:
         # timed AT the scale the scaler settled at (round 2 timed two halvings below it: fewer binary16 gradients survive
         # there, so the scatter did less work than a training run's).  A timed step may still overflow - GradScaler
@@ -708,6 +774,11 @@ def main():
                 "nonzero_fraction_per_point": [float(v) for v in c["nonzero_fraction_per_point"].tolist()]}
         del raw
         torch.cuda.empty_cache()
+    cpu_result = None
+    if cpu_child is not None:
+        t_w = time.perf_counter()
+        cpu_result = cpu_baseline_collect(cpu_child, args.workload)
+        log(f"cpu baseline: child finished (waited {time.perf_counter() - t_w:.1f} s for it before the timed region)")
     elapsed, prof, info = run(*HEADLINE, args.steps, args.warmup)
     log(f"headline: {1e3 * elapsed / args.steps:.1f} ms/step, {info['applied']} of {args.steps * views} updates applied, "
         f"loss scale {info['scale_before']} -> {info['scale_after']}, peak memory {info['peak_mem_GiB']:.1f} GiB")
@@ -764,12 +835,14 @@ def main():
                     for prm in clip_model.parameters():
                         prm.requires_grad_(not frozen)
                     step_extra.update(t=300, clip_model=clip_model, ref_rgb=ref_rgb, ref_text="a toy")
+                    # (the unfrozen figure is context - what the reference wastes - and gets 2 steps unless --all-variants)
+                    vs = args.variant_steps if (frozen or args.all_variants) else min(2, args.variant_steps)
                     try:   # (two warm-up steps: the CLIP towers' weight-gradient kernels are first used here)
-                        e, cprof, cinfo = run("fp32", "reference", args.variant_steps, 2)
+                        e, cprof, cinfo = run("fp32", "reference", vs, 2 if frozen else 1)
                     finally:
                         step_extra.clear()
                         clip_model.zero_grad(set_to_none=True)
-                    variants[label] = 1e3 * e / args.variant_steps
+                    variants[label] = 1e3 * e / vs
                     if frozen:
                         clip_step = {"ms_per_step": variants[label], "t": 300,
                                      "optimizer_steps_applied": cinfo["applied"],
@@ -949,9 +1022,8 @@ def main():
                 line["reference_shaped_baseline"] = {"value": None, "error": repr(e)}
             if line["reference_shaped_baseline"].get("value"):
                 line["speedup_vs_reference_shaped"] = line["value"] / line["reference_shaped_baseline"]["value"]
-        if not args.no_cpu_baseline:
-            log("cpu baseline (child processes, hard limit 150 s per leg)")
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+        if cpu_result is not None:
+            line["cpu_baseline"] = cpu_result
             try:
                 line["cpu_baseline"]["product_c1_gpu"] = product_c1_gpu(dev)
                 fb = line["cpu_baseline"].get("forward_backward_ms")
@@ -1084,7 +1156,7 @@ def bench_refine(args, wl, dev, rank, world):
         dist.destroy_process_group()
 
 
-def reference_shaped(model, guidance, text_z, opt, rays, wl, t_fixed, dev, init_scale, steps=2):
+def reference_shaped(model, guidance, text_z, opt, rays, wl, t_fixed, dev, init_scale, steps=1, mark=False):
     """The reference's own NeRFNetwork + NeRFRenderer.run_cuda Python (staged, oracle/_ref/py) on the drop-in
     raymarching / tinycudann packages: same weights, same step (two-backward schedule, fp16 autocast, Adan)."""
     import torch
@@ -1109,11 +1181,17 @@ def reference_shaped(model, guidance, text_z, opt, rays, wl, t_fixed, dev, init_
     first = time.perf_counter() - t0
     log(f"reference-shaped warm-up step: {first:.2f} s")
     steps = 1 if first > 15 else steps   # bounded: the leg must not stretch the default run
+    if mark:   # marker dispatches either side of the timed steps (tools/trace_sum.py --window spin_kernel)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if mark:
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     del ref_model, optimizer
     torch.cuda.empty_cache()

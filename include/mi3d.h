@@ -32,7 +32,8 @@ extern "C" {
 #define MI3D_MAX_LEVELS 16
 #define MI3D_MAX_POINTS 16
 
-/* the ABI version: 4 (3 + the compact-round inference loop of Part 1b; every version-3 entry point is unchanged) */
+/* the ABI version: 5 (4 = 3 + the compact-round inference loop of Part 1b; 5: that loop's ctl block is int32[16] with
+ * the dropped-row count in [8], and its plan never passes max_steps; every other entry point is unchanged) */
 int mi3d_abi_version(void);
 const char *mi3d_last_error_string(int err);
 
@@ -130,13 +131,17 @@ int mi3d_compact_alive_ctl(int32_t *ctl, const int32_t *rays_alive_in, int32_t *
  * are cut into rounds (it carries t in rays_t and its transmittance in weights_sum), so here a round takes
  * n_step = clamp(budget / n_alive, step_min, step_max) steps and the march packs what the rays actually emitted into one
  * slab per ray (wave scan + one atomic per wave on ctl[2], as the training march does): a render is a handful of rounds
- * and no row of a finished ray is evaluated.  ctl (int32[8]): [0] n_alive, [1] n_step, [2] rows of this round (written by
- * the march, zeroed by begin / compact), [3] steps done, [4] rounds done, [5] budget, [6] step_min, [7] step_max.
+ * and no row of a finished ray is evaluated.  ctl (int32[16], ABI version 5; version 4: int32[8]): [0] n_alive, [1] n_step,
+ * [2] rows of this round (written by the march, zeroed by begin / compact), [3] steps done, [4] rounds done, [5] budget,
+ * [6] step_min, [7] step_max, [8] rows DROPPED so far because a ray's slab would have passed rows_cap (sticky; zeroed by
+ * begin2; non-zero = the render is incomplete: the caller's rows_cap is below max(budget, N step_min)), [9..15] reserved.
+ * The plan never lets steps done + n_step pass max_steps (a ray takes at most max_steps steps whatever the budget).
  *   mi3d_infer_begin2            rays_alive[i] = i, ctl for round 0
  *   mi3d_march_rays_compact_ctl  ray_slab int32[n_alive_max][2] = (first row, rows) per alive slot; t_next f32[n_alive_max] =
  *                                the march's own t behind its last step (what the next round resumes from: the restart is
  *                                exact, so the sample sequence of a ray is the same for every budget); a ray whose slab
- *                                would pass rows_cap emits nothing (cannot happen when rows_cap >= max(budget, N step_min))
+ *                                would pass rows_cap emits nothing and its rows are counted in ctl[8] (cannot happen when
+ *                                rows_cap >= max(budget, N step_min))
  *   mi3d_composite_rays_compact_ctl  composite_rays over each ray's slab; a ray that used all n_step rows resumes at t_next
  *   mi3d_compact_alive_ctl2      the compaction + the next round's plan                                       */
 int mi3d_infer_begin2(int32_t *ctl, int32_t *rays_alive, uint32_t N, uint32_t budget_rows, uint32_t step_min,

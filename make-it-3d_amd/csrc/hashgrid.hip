@@ -469,7 +469,9 @@ __device__ __forceinline__ void encode_points(const PointSet &ps, const float (&
 constexpr uint32_t kPlanSlots = 64;
 __device__ uint32_t g_encode_next[kPlanSlots * kXcds * kMaxSegs];
 // host side of the ring (mi3d_grid_encode_points_planes_counted): who used a slot last, and the event behind that launch
-struct PlanSlot { bool used = false; hipStream_t stream = nullptr; hipEvent_t done = nullptr; int device = -1; };
+// (`broken`: the event behind the slot's last launch could not be recorded - nobody can tell any more when that launch is
+//  over, so the slot is never handed out again: launches that draw it deal their tiles statically)
+struct PlanSlot { bool used = false; bool broken = false; hipEvent_t done = nullptr; int device = -1; };
 PlanSlot g_slots[kPlanSlots];
 uint32_t g_slot_launches = 0;
 std::mutex g_slot_mutex;
@@ -2206,8 +2208,8 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     const int triple = MI3D_TUNE(MI3D_T_ENCODE_TRIPLE, MI3D_ENCODE_TRIPLE);
     const bool split = triple != 0 && fine_mask != 0u && (variant & 3) == 3;
     // One counter slot per launch, a ring of 64, zeroed in-stream right before the kernel; a hipEvent recorded behind the
-    // kernel says when the slot is free again.  A slot coming round on the stream that used it last is free by stream
-    // order; on any other stream only once its event has completed - otherwise the launch leaves the slot alone and deals
+    // kernel says when the slot is free again: a slot is handed out only once that event has completed (whatever the
+    // stream) - otherwise the launch leaves the slot alone and deals
     // its tiles statically (next == nullptr: the round-2 order, same planes, a few ms slower at C2 size) - never two live
     // launches on one set of counters.  (Round 4 asked the previous owner's STREAM with hipStreamQuery: a destroyed
     // stream's handle is not a valid argument, and a launch captured into a hipGraph recorded the idle capture stream as
@@ -2226,8 +2228,12 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
         std::lock_guard<std::mutex> guard(g_slot_mutex);
         const uint32_t slot = g_slot_launches++ % kPlanSlots;
         PlanSlot &ps_slot = g_slots[slot];
-        bool free_now = !ps_slot.used || ps_slot.stream == st;
-        if (!free_now) {   // (hipEventQuery does not block; hipErrorNotReady is not a failure of this call)
+        // free = never used, or the event recorded behind its last launch has completed.  (Round 5 also took a slot whose
+        // last user was "this stream" by comparing raw handles: a destroyed stream's address can come back as another
+        // stream's while the old launch is still running - ADVICE round 5.  The event is the only witness now; a slot that
+        // comes round on a stream with 64 gathers still in flight deals statically instead.)
+        bool free_now = !ps_slot.used;
+        if (!free_now && !ps_slot.broken && ps_slot.done != nullptr) {   // (hipEventQuery does not block; hipErrorNotReady is not a failure)
             free_now = hipEventQuery(ps_slot.done) == hipSuccess;
             if (!free_now) (void)hipGetLastError();
         }
@@ -2248,7 +2254,6 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
         }
         if (free_now) {
             ps_slot.used = true;
-            ps_slot.stream = st;
             next = base + (size_t)slot * kXcds * kMaxSegs;
             e = hipMemsetAsync(next, 0, sizeof(uint32_t) * kXcds * kMaxSegs, st);
             if (e != hipSuccess) return (int)e;
@@ -2259,7 +2264,10 @@ int mi3d_grid_encode_points_planes_counted(const float *x, const float *x2, uint
     auto slot_done = [&](int slot_used) {   // behind the kernel: the slot's counters are free once this event has completed
         if (slot_used >= 0) {
             std::lock_guard<std::mutex> guard(g_slot_mutex);
-            if (hipEventRecord(g_slots[slot_used].done, st) != hipSuccess) (void)hipGetLastError();
+            if (hipEventRecord(g_slots[slot_used].done, st) != hipSuccess) {
+                (void)hipGetLastError();
+                g_slots[slot_used].broken = true;   // a stale event would report "complete" while the kernel still runs
+            }
         }
     };
     const dim3 block(kWave * kWaves);

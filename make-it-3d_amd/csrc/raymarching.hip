@@ -600,7 +600,17 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
         const int32_t done = n_alive != 0u ? ctl[CTL_DONE] + ctl[CTL_STEP] : ctl[CTL_DONE];
         int32_t alive = (int32_t)base_s;
         if (done >= (int32_t)max_steps) alive = 0;  // `while step < max_steps` of the reference loop
-        if (BUDGET) infer_plan2(alive, ctl); else infer_plan(alive, N, align, ctl);
+        if (BUDGET) {
+            infer_plan2(alive, ctl);
+            // never plan past the loop's end: the reference's `while step < max_steps` overshoots by at most n_step - 1 <= 7
+            // steps; a budget round of hundreds of steps would let a ray that is still alive there (bound > 1, dt_gamma = 0)
+            // take up to max_steps - 1 more - by an amount that depends on the budget.  With the cap a
+            // ray takes at most max_steps steps, whatever the budget.
+            const int32_t left = (int32_t)max_steps - done;
+            if (alive > 0 && ctl[CTL_STEP] > left) ctl[CTL_STEP] = left > 1 ? left : 1;
+        } else {
+            infer_plan(alive, N, align, ctl);
+        }
         ctl[CTL_DONE] = done;
         if (n_alive != 0u) ctl[CTL_ROUNDS] += 1;   // (a round launched after the last ray died is not a round of the loop)
     }
@@ -619,7 +629,10 @@ __global__ __launch_bounds__(1024) void k_compact_alive_ctl(int32_t *__restrict_
 // not the composite's running sum of the float differences deltas[.,1] (equal whenever those sums are exact, i.e. almost
 // always): a ray's sample sequence is then EXACTLY the uninterrupted march's, whatever the budget - two budgets give
 // bit-identical images (tests/test_raymarching_gpu.py).
-enum : int { CTL_BUDGET = 5, CTL_STEP_MIN = 6, CTL_STEP_MAX = 7 };
+// (ABI version 5: the budget loop's ctl is int32[16]; [8] = rows the march could not place because a ray's slab would have
+//  passed rows_cap - a sticky count, zeroed by begin2, that the host looks at when it reads the block: the drop used to be
+//  silent)
+enum : int { CTL_BUDGET = 5, CTL_STEP_MIN = 6, CTL_STEP_MAX = 7, CTL_DROPPED = 8 };
 
 __device__ __forceinline__ void infer_plan2(int32_t n_alive, int32_t *ctl) {
     int32_t n_step = 0;
@@ -638,7 +651,7 @@ __global__ void k_infer_begin2(int32_t *__restrict__ ctl, int32_t *__restrict__ 
     if (i == 0) {
         ctl[CTL_BUDGET] = (int32_t)budget; ctl[CTL_STEP_MIN] = (int32_t)step_min; ctl[CTL_STEP_MAX] = (int32_t)step_max;
         infer_plan2((int32_t)N, ctl);
-        ctl[CTL_DONE] = 0; ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_DONE] = 0; ctl[CTL_ROUNDS] = 0; ctl[CTL_DROPPED] = 0;
     }
 }
 
@@ -681,7 +694,10 @@ __global__ __launch_bounds__(128) void k_march_infer_compact_ctl(
     if (lane == 0 && wave_total != 0u) base = (uint32_t)atomicAdd(ctl + CTL_ROWS, (int)wave_total);
     base = __shfl(base, 0, kWave);
     uint32_t offset = base + incl - count;
-    if (offset + count > rows_cap) count = 0;   // (cannot happen with rows_cap >= max(budget, N step_min): dropped, not an error)
+    if (offset + count > rows_cap) {   // cannot happen with rows_cap >= max(budget, N step_min); if it does the ray emits
+        if (count != 0u) atomicAdd(ctl + CTL_DROPPED, (int)count);   // nothing this round and the host is TOLD (ctl[8], sticky)
+        count = 0;
+    }
     if (!live) return;
     ray_slab[(size_t)n * 2] = (int32_t)offset;
     ray_slab[(size_t)n * 2 + 1] = (int32_t)count;
@@ -750,7 +766,7 @@ __global__ void k_composite_infer_compact_ctl(const int32_t *__restrict__ ctl, f
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 4; }
+int mi3d_abi_version(void) { return 5; }
 const char *mi3d_last_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
 int mi3d_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,

@@ -35,6 +35,10 @@ class FlatGradBucket:
                 raise ValueError("all bucketed parameters must share device and dtype")
             p.grad = self.flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the bucket
             off += p.numel()
+        # this bucket reads `.grad` from Python (GridParameter.grad completes a parked scatter first): the deferred point-0
+        # scatter stays on under a process group (grid_ops.deferral_allowed)
+        from . import grid_ops
+        grid_ops.PYTHON_GRAD_SYNC = True
 
     @property
     def nbytes(self):

@@ -185,11 +185,11 @@ def _may_defer(param, P, P_active):
     the table is a GridParameter (its `.grad` completes the scatter for any reader); the pass stops at point 0 of a wider
     stencil; it runs under retain_graph=True, i.e. the caller announced another pass through this forward (nerf/sd.py:171
     does); and the engine is accumulating into `.grad` rather than returning gradients."""
-    if not (grid_ops.DEFER_POINT0 and isinstance(param, grid_ops.GridParameter) and P_active == 1 and P > 1):
-        return False
+    if not (grid_ops.deferral_allowed() and isinstance(param, grid_ops.GridParameter) and P_active == 1 and P > 1):
+        return False   # (deferral_allowed: off under a process group whose gradient sync is not mi3d.dp's - torch DDP)
     if getattr(param, "_post_accumulate_grad_hooks", None):
-        # torch DDP / FSDP (and any register_post_accumulate_grad_hook user) read the gradient from C++ right after this
-        # pass: they would miss what is parked - scatter now (grid_ops.DEFER_POINT0's note)
+        # FSDP and any register_post_accumulate_grad_hook user read the gradient right after this pass: they would miss
+        # what is parked - scatter now (grid_ops.DEFER_POINT0's note)
         return False
     try:
         keep = torch._C._autograd._get_current_graph_task_keep_graph()
@@ -309,7 +309,12 @@ def field_stencil(params, layers, x, offsets, cfg, bound=1.0, x2=None, P0=None, 
                                _half_mode(half_mode))
 
 
-def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon, count=None):
+def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsilon, count=None, half_mode=False):
+    """`half_mode`: under torch.autocast(float16) the reference's `torch.sigmoid(h[..., 1:])` (network_tcnn.py:110) takes
+    the binary16 MLP output and RETURNS binary16 - its albedo carries 11 significant bits into the compositor.  The albedo
+    here keeps its fp32 buffer but holds those rounded values (sigma does not change: `h[..., 0] + gaussian(x)` promotes
+    to fp32 and trunc_exp casts to fp32, activation.py:7).  Round 5 left the albedo unrounded: that was the whole of the
+    4e-5 / 8.4e-5 image difference to the reference route under autocast (profiles/headline_parity_r05.json)."""
     P, n, dev = offs.shape[0], x.shape[0], x.device
     alloc = torch.empty if count is None else torch.zeros   # rows beyond a device count are not written: keep them defined
     sigma = alloc(n, dtype=torch.float32, device=dev)
@@ -320,6 +325,8 @@ def _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius, epsi
         "mi3d_field_head_forward_counted", L.ptr(h), L.ptr(x), L.ptr(x2), n, L.ptr(count), offs_p, P, float(bound),
         float(blob_density), float(blob_radius), float(epsilon), L.ptr(sigma), L.ptr(albedo), L.ptr(normal),
         L.ptr(normal2), L.stream(x)), n)
+    if half_mode:
+        albedo.copy_(albedo.to(torch.float16))
     return sigma, albedo, normal, normal2
 
 
@@ -409,7 +416,7 @@ class _Field(Function):
         with L.on(x):
             feats, h, dims = _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mode, step)
             sigma, albedo, normal, normal2 = _head_forward(h, x, x2, offs, offs_p, bound, blob_density, blob_radius,
-                                                           epsilon)
+                                                           epsilon, half_mode=half_mode)
         ctx.save_for_backward(x, x2 if x2 is not None else x, feats, h, *ws)
         ctx.meta = (offs, int(P0), float(bound), cfg, float(step), x2 is not None, params.numel(), dims,
                     int(half_mode), float(blob_density), float(blob_radius), float(epsilon))
@@ -465,8 +472,10 @@ def field_rows(params, layers, x, offsets, cfg, bound, blob_density, blob_radius
         raise L.Mi3dError("field_rows takes the 7-point stencil")
     count = L.dev_typed(count, "count", torch.int32)
     with L.on(x):
-        _, h, _ = _forward_encode_mlp(params, ws, x, None, offs, offs_p, 7, bound, cfg, _half_mode(half_mode), step, count)
-        sigma, albedo, normal, _ = _head_forward(h, x, None, offs, offs_p, bound, blob_density, blob_radius, epsilon, count)
+        hm = _half_mode(half_mode)
+        _, h, _ = _forward_encode_mlp(params, ws, x, None, offs, offs_p, 7, bound, cfg, hm, step, count)
+        sigma, albedo, normal, _ = _head_forward(h, x, None, offs, offs_p, bound, blob_density, blob_radius, epsilon, count,
+                                                 half_mode=hm)
     return sigma, albedo, normal
 
 

@@ -95,9 +95,17 @@ class NeRFNetwork(NeRFRenderer):
         d = (x ** 2).sum(-1)
         return self.opt.blob_density * torch.exp(-d / (2 * self.opt.blob_radius ** 2))
 
+    @staticmethod
+    def _sigmoid(h):
+        """network_tcnn.py:110 under torch.autocast(float16): the MLP output is binary16 there, so torch.sigmoid returns
+        binary16.  The fused MLP hands back an fp32 buffer of binary16-representable values: cast it back first."""
+        if h.is_cuda and field_ops._half_mode(None):
+            h = h.to(torch.float16)
+        return torch.sigmoid(h)
+
     def _head(self, h, x):
         sigma = trunc_exp(h[..., 0] + self.gaussian(x))
-        albedo = torch.sigmoid(h[..., 1:])
+        albedo = self._sigmoid(h[..., 1:])
         return sigma, albedo
 
     def _encode(self, x, offsets, x2=None, P0=None, step=0.0):
@@ -156,7 +164,7 @@ class NeRFNetwork(NeRFRenderer):
             return field_ops.field(self.encoder.params, self.sigma_net.net, x, offs, self.encoder.cfg, float(self.bound),
                                    self.opt.blob_density, self.opt.blob_radius, x2, P0 if x2 is not None else None, step)
         sig, h = self._stencil_sigma(x, offs, x2, P0 if x2 is not None else None, step)
-        albedo = torch.sigmoid(h[:, 0, 1:])
+        albedo = self._sigmoid(h[:, 0, 1:])
         normals = self._normal_from(sig[:, 1:7])
         normals_jitter = self._normal_from(sig[:, 7:13]) if x2 is not None else None
         return sig[:, 0], albedo, normals, normals_jitter

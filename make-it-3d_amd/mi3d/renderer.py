@@ -319,7 +319,7 @@ class NeRFRenderer(nn.Module):
                   "fars": torch.empty(N, **f32), "rays_t": torch.empty(N, **f32), "light_d": torch.empty(3, **f32),
                   "xyzs": torch.zeros(rows_cap, 3, **f32), "dirs": torch.zeros(rows_cap, 3, **f32),
                   "deltas": torch.zeros(rows_cap, 2, **f32), "noise_buf": torch.zeros(N, **f32),
-                  "ctl": torch.zeros(8, **i32), "alive": torch.empty(N, **i32), "spare": torch.empty(N, **i32),
+                  "ctl": torch.zeros(16, **i32), "alive": torch.empty(N, **i32), "spare": torch.empty(N, **i32),
                   "ray_slab": torch.zeros(N, 2, **i32), "t_next": torch.zeros(N, **f32),
                   "weights_sum": torch.zeros(N, **f32), "depth": torch.zeros(N, **f32),
                   "image": torch.zeros(N, 3, **f32), "normal": torch.zeros(N, 3, **f32)}
@@ -433,6 +433,11 @@ class NeRFRenderer(nn.Module):
                     state = st["ctl"].tolist()               # the only synchronisation: once per replay
                     alive = state[0]
                     stats["host_reads"] += 1
+            if len(state) > 8 and state[8]:
+                # (cannot happen with the buffers this module allocates - rows_cap >= max(budget, N); the march counts what
+                #  it could not place instead of dropping it silently: C ABI version 5, ctl[8])
+                raise raymarching.L.Mi3dError(f"inference march dropped {state[8]} rows: the sample buffers hold fewer rows "
+                                              f"than max(budget, N)")
         else:
             raymarching.infer_begin(N, device, st["align"], st["ctl"], st["alive"])
             R = int(self.infer_graph_rounds)

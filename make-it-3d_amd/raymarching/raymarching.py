@@ -361,8 +361,10 @@ def compact_alive_ctl(ctl, rays_alive_in, rays_alive_out, N, align=128, max_step
 
 def infer_begin2(N, device, budget_rows, step_min=1, step_max=1024, ctl=None, rays_alive=None):
     if ctl is None:
-        ctl = torch.zeros(8, dtype=torch.int32, device=device)
+        ctl = torch.zeros(16, dtype=torch.int32, device=device)
     else:
+        if ctl.numel() < 16:
+            raise L.Mi3dError("the budget loop's ctl block is int32[16] (ABI version 5: ctl[8] counts dropped rows)")
         L.dev_typed(ctl, "ctl", torch.int32).zero_()
     if rays_alive is None:
         rays_alive = torch.empty(N, dtype=torch.int32, device=device)

@@ -11,8 +11,10 @@
  * half_mode = 1 : emulates torch.autocast(fp16) around the nn.Linear stack the way
  *                 the reference trains (nerf/utils.py:979): encoder output (fp32) and the
  *                 fp32 master weights/bias are rounded to fp16, products accumulate in fp32,
- *                 each layer's output is rounded to fp16; the head (blob, exp, sigmoid) is
- *                 evaluated in fp32 on the fp16-rounded MLP output.
+ *                 each layer's output is rounded to fp16; the blob and trunc_exp are evaluated
+ *                 in fp32 on the fp16-rounded MLP output (h[..., 0] + gaussian(x) promotes to fp32,
+ *                 activation.py:7 casts to fp32), while torch.sigmoid(h[..., 1:]) of the fp16 tensor
+ *                 (network_tcnn.py:110) RETURNS fp16: the albedo is rounded to fp16 as well.
  */
 #include <math.h>
 #include <stdint.h>
@@ -95,7 +97,10 @@ ORACLE_API void ref_field_density(const float *x, uint32_t n, float bound, const
         /* :98 - python evaluates 2*r**2 in double, torch then divides the fp32 tensor by that scalar */
         const float g = (float)blob_density * expf(-d / (float)(2 * blob_radius * blob_radius));
         sigma[i] = expf(h[0] + g);                                              /* :109 trunc_exp fwd */
-        for (int c = 0; c < 3; c++) albedo[(size_t)i * 3 + c] = 1.0f / (1.0f + expf(-h[1 + c])); /* :110 */
+        for (int c = 0; c < 3; c++) {                                           /* :110 */
+            const float a = 1.0f / (1.0f + expf(-h[1 + c]));
+            albedo[(size_t)i * 3 + c] = half_mode ? round_half(a) : a;          /* sigmoid(fp16) -> fp16 */
+        }
         if (raw) memcpy(raw + (size_t)i * 4, h, sizeof h);
     }
     free(h01); free(feat);

@@ -100,8 +100,12 @@ def install():
     import importlib.util as iu
     keep = []
     for r in _STUB_ROOTS:
-        if r == "clip":
-            keep.append(r)
+        if r in ("clip", "matplotlib", "pandas"):
+            # always stubbed: `clip` would resolve to an unrelated package; nerf/utils.py imports matplotlib.pyplot and
+            # pandas for plotting / logging only, and the real imports cost tens of seconds on a fresh box (matplotlib
+            # builds its font cache: 20-30 s of bench.py's reference-shaped leg in round 5)
+            if r not in sys.modules:
+                keep.append(r)
             continue
         try:
             if iu.find_spec(r) is None:

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 19
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.mi3d_abi_version() == 4
+    assert lib.mi3d_abi_version() == 5
 
 
 def test_python_binding_covers_the_abi():

@@ -93,6 +93,27 @@ def test_deferral_is_off_for_parameters_with_post_accumulate_grad_hooks():
     assert field_ops._may_defer(p, 13, 1) is False
 
 
+def test_deferral_is_off_under_a_process_group_unless_the_python_bucket_syncs(tmp_path):
+    """torch DDP's reducer hooks the AccumulateGrad node in C++ - no Python-visible attribute gives it away (ADVICE round 5:
+    the post-accumulate-grad test above does NOT cover it).  So under ANY initialised process group nothing is parked,
+    unless the gradient sync is mi3d.dp.FlatGradBucket, which reads `.grad` through GridParameter.grad and says so."""
+    import torch.distributed as dist
+    from mi3d import dp, grid_ops
+    assert grid_ops.deferral_allowed()
+    was = grid_ops.PYTHON_GRAD_SYNC
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        grid_ops.PYTHON_GRAD_SYNC = False
+        assert not grid_ops.deferral_allowed()                       # e.g. the reference trainer's DDP wrap
+        p = grid_ops.GridParameter(torch.zeros(8))
+        dp.FlatGradBucket([p])
+        assert grid_ops.PYTHON_GRAD_SYNC and grid_ops.deferral_allowed()
+    finally:
+        dist.destroy_process_group()
+        grid_ops.PYTHON_GRAD_SYNC = was
+    assert grid_ops.deferral_allowed()
+
+
 def test_eval_round_budget_and_schedule_defaults():
     """mi3d.renderer's compact eval rounds (DESIGN.md 3.5'): the row budget a round gets - 16 rows per ray, at least 2^18,
     at most max(2^21, 2 N) - and the attributes a user may set."""

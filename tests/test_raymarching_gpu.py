@@ -18,7 +18,7 @@ def T(a, dev):
 
 def test_loads_native_library(cuda):
     from mi3d import _lib
-    assert _lib.lib().mi3d_abi_version() == 4
+    assert _lib.lib().mi3d_abi_version() == 5
 
 
 def test_near_far_bit_exact(cuda, oracle):
@@ -303,6 +303,106 @@ def test_inference_march_composite_loop(cuda, oracle):
     np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=RTOL, atol=1e-6)
     np.testing.assert_allclose(nrm.cpu().numpy(), nrm_r, rtol=RTOL, atol=1e-6)
     np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=RTOL, atol=1e-5)
+
+
+def test_compact_budget_rounds_kernels_against_oracle(cuda, oracle):
+    """The four entry points of the budget loop (C ABI Part 1b, second half: mi3d_infer_begin2, mi3d_march_rays_compact_ctl,
+    mi3d_composite_rays_compact_ctl, mi3d_compact_alive_ctl2) driven directly, round by round, against the CPU oracle's
+    march_rays / composite_rays (raymarching.cu:906-1115 restated): the plan in the control block, the slab packing (one
+    slab per ray, slabs tile [0, rows) exactly), every slab row bit-exact, the accumulators, the death rule, the
+    order-preserving compaction, the restart point (t_next = the march's own t, which the reference's running sum of
+    deltas[:, 1] reproduces to float rounding) and the step cap (the only coverage used to be the
+    end-to-end render comparison)."""
+    import raymarching
+    rng = np.random.default_rng(31)
+    N, H, max_steps, budget = 600, 128, 96, 2500
+    o, d = make_rays(rng, N)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb)
+    bits = sphere_bitfield(oracle, 1, H, 0.6)
+
+    def field(x):
+        s = (6 * np.exp(-np.sum(x * x, 1) / 0.08)).astype(np.float32)
+        c = (0.5 + 0.5 * np.sin(x * 7)).astype(np.float32)
+        nrm = (x / (np.linalg.norm(x, axis=1, keepdims=True) + 1e-6)).astype(np.float32)
+        return s, c, nrm
+
+    ws_r, dep_r = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    img_r, nrm_r = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32)
+    alive_r, t_r = np.arange(N, dtype=np.int32), nears.copy()
+    ws, dep = torch.zeros(N, device=cuda), torch.zeros(N, device=cuda)
+    img, nrm = torch.zeros(N, 3, device=cuda), torch.zeros(N, 3, device=cuda)
+    t = T(nears, cuda).clone()
+    rows_cap = max(budget, N)
+    xyzs, dirs = torch.zeros(rows_cap, 3, device=cuda), torch.zeros(rows_cap, 3, device=cuda)
+    deltas = torch.zeros(rows_cap, 2, device=cuda)
+    slab, t_next = torch.zeros(N, 2, dtype=torch.int32, device=cuda), torch.zeros(N, device=cuda)
+    ctl, alive = raymarching.infer_begin2(N, cuda, budget, 1, max_steps)
+    spare = torch.empty_like(alive)
+    assert ctl.numel() == 16
+    od, dd, bd, fd = T(o, cuda), T(d, cuda), T(bits, cuda), T(fars, cuda)
+    done, rounds = 0, 0
+    while True:
+        st = ctl.tolist()
+        n_alive, n_step = st[0], st[1]
+        assert n_alive == alive_r.shape[0] and st[3] == done and st[4] == rounds and st[8] == 0
+        if n_alive == 0:
+            break
+        assert n_step == max(1, min(budget // n_alive, max_steps, max_steps - done)), (st, done)   # the plan, capped
+        raymarching.march_rays_compact_ctl(ctl, N, alive, t, od, dd, 1.0, bd, 1, H, fd, xyzs, dirs, deltas, slab, t_next,
+                                           None, 0, max_steps)
+        rows = int(ctl[2])
+        xr, dr, lr = oracle.march_rays(n_alive, n_step, alive_r, t_r, o, d, 1.0, bits, 1, H, nears, fars, align=-1,
+                                       max_steps=max_steps)
+        cnt_r = (lr[:, 0].reshape(n_alive, n_step) != 0).sum(1)
+        sl = slab[:n_alive].cpu().numpy()
+        assert np.array_equal(sl[:, 1], cnt_r) and rows == int(cnt_r.sum())
+        order = np.argsort(sl[:, 0], kind="stable")
+        nz = order[sl[order, 1] > 0]
+        assert np.array_equal(sl[nz, 0], np.concatenate([[0], np.cumsum(sl[nz, 1])[:-1]]))      # slabs tile [0, rows)
+        xg, dg, lg = xyzs[:rows].cpu().numpy(), dirs[:rows].cpu().numpy(), deltas[:rows].cpu().numpy()
+        gather = np.concatenate([np.arange(i * n_step, i * n_step + c) for i, c in enumerate(cnt_r)]).astype(np.int64) \
+            if rows else np.zeros(0, np.int64)
+        place = np.concatenate([np.arange(sl[i, 0], sl[i, 0] + c) for i, c in enumerate(cnt_r)]).astype(np.int64) \
+            if rows else np.zeros(0, np.int64)
+        assert np.array_equal(xg[place], xr[gather]) and np.array_equal(dg[place], dr[gather])   # every slab row, bit-exact
+        assert np.array_equal(lg[place], lr[gather])
+        s_r, c_r, n_r = field(xr)
+        s_g, c_g, n_g = field(xg)
+        oracle.composite_rays(n_alive, n_step, alive_r, t_r, s_r, c_r, n_r, lr, ws_r, dep_r, img_r, nrm_r, 1e-2)
+        pad = lambda a, w: T(np.concatenate([a, np.zeros((rows_cap - rows,) + a.shape[1:], np.float32)]), cuda)  # noqa: E731
+        raymarching.composite_rays_compact_ctl(ctl, N, alive, t, slab, t_next, pad(s_g, 1), pad(c_g, 3), pad(n_g, 3), deltas,
+                                               ws, dep, img, nrm, 1e-2)
+        a_g = alive[:n_alive].cpu().numpy()
+        assert np.array_equal(a_g >= 0, alive_r >= 0)                                            # the death rule
+        np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(nrm.cpu().numpy(), nrm_r, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=1e-6, atol=1e-6)
+        keep = alive_r >= 0
+        # the restart: the march's own t for a survivor; the reference's running sum agrees to float rounding
+        t_g = t.cpu().numpy()
+        np.testing.assert_allclose(t_g[alive_r[keep]], t_r[alive_r[keep]], rtol=0, atol=2e-5)
+        assert np.array_equal(t_g[alive_r[keep]], t_next[:n_alive].cpu().numpy()[keep])
+        t_r[alive_r[keep]] = t_g[alive_r[keep]]     # (both sides start the next round from the same t)
+        raymarching.compact_alive_ctl2(ctl, alive, spare, N, max_steps)
+        alive, spare = spare, alive
+        alive_r = alive_r[keep]
+        done += n_step
+        rounds += 1
+        if done >= max_steps:
+            alive_r = alive_r[:0]
+        assert np.array_equal(alive[:alive_r.shape[0]].cpu().numpy(), alive_r)                   # compaction keeps the order
+    assert rounds >= 3 and done <= max_steps + 0 or alive_r.shape[0] == 0
+    assert float(ws_r.max()) > 0.5
+
+    # a sample buffer smaller than the round needs: the rows are COUNTED in ctl[8], not dropped silently
+    ctl, alive = raymarching.infer_begin2(N, cuda, budget, 1, max_steps)
+    small = 64
+    raymarching.march_rays_compact_ctl(ctl, N, alive, T(nears, cuda).clone(), od, dd, 1.0, bd, 1, H, fd, xyzs[:small],
+                                       dirs[:small], deltas[:small], slab, t_next, None, 0, max_steps)
+    st = ctl.tolist()
+    assert st[8] > 0 and st[8] + int(slab[:, 1].sum()) == st[2]
 
 
 def test_rejects_bad_inputs(cuda):
