@@ -106,6 +106,24 @@ class NeRFRenderer(nn.Module):
     def shade(self, albedo, normal, light_d, ratio, shading):
         raise NotImplementedError()
 
+    def reset_extra_state(self):
+        """renderer.py:144-155."""
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    def export_mesh(self, path, resolution=None, S=128):
+        """renderer.py:157-330 (marching cubes + xatlas + nvdiffrast texture baking, reached only through main.py's
+        `--save_mesh`): out of this path's scope (mesh export) - said loudly instead of by AttributeError."""
+        raise NotImplementedError("export_mesh (--save_mesh) is outside the SDS training hot path this package covers; load "
+                                  "the checkpoint into the reference's own class (nerf.network_tcnn.NeRFNetwork_reference "
+                                  "under mi3d.autopatch: same state_dict keys) to export a mesh")
+
     # --- pure-PyTorch sampler path (BASELINE config 1) --------------------------------------------
     def run(self, rays_o, rays_d, ref_bg=None, num_steps=128, upsample_steps=128, light_d=None, ambient_ratio=1.0,
             shading="albedo", bg_color=None, perturb=False, **kwargs):

@@ -163,7 +163,9 @@ def reference_network(opt, encoder="oracle", **kw):
         ref_renderer.raymarching = raymarching
     else:
         raise ValueError(encoder)
-    return ref_net.NeRFNetwork(opt, **kw)
+    # (under mi3d.autopatch the module's `NeRFNetwork` is the fused class; the reference's own stays reachable)
+    cls = getattr(ref_net, "NeRFNetwork_reference", None) or ref_net.NeRFNetwork
+    return cls(opt, **kw)
 
 
 def default_opt(**over):
