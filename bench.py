@@ -590,7 +590,7 @@ def main():
         return bench_refine(args, wl, dev, rank, world)
     views = wl["views"]
 
-    from mi3d import dp, grid_ops, rays as R, sd_standin, sds_step
+    from mi3d import dp, field_ops as field_ops_mod, grid_ops, rays as R, sd_standin, sds_step
     opt = sds_step.make_opt(max_steps=wl["max_steps"])
     # GradScaler: the reference constructs it at 65536 (nerf/utils.py:309).  On this workload the normal-smoothness
     # regulariser back-propagates through safe_normalize of finite differences that fp16 rounds to exactly zero
@@ -838,7 +838,7 @@ def main():
                     # (the unfrozen figure is context - what the reference wastes - and gets 2 steps unless --all-variants)
                     vs = args.variant_steps if (frozen or args.all_variants) else min(2, args.variant_steps)
                     try:   # (two warm-up steps: the CLIP towers' weight-gradient kernels are first used here)
-                        e, cprof, cinfo = run("fp32", "reference", vs, 2 if frozen else 1)
+                        e, cprof, cinfo = run("fp32", "reference", vs, 2)
                     finally:
                         step_extra.clear()
                         clip_model.zero_grad(set_to_none=True)
@@ -974,6 +974,9 @@ def main():
             # exclusive phases of the step (HIP events on the launch stream): their sum is the step
             "phases_ms_per_step": {k[6:]: sum(v) / args.steps for k, v in ms.items() if k.startswith("phase:")},
             "peak_mem_GiB": info["peak_mem_GiB"],
+            # which of the candidate blocks the persistent record arena was placed on, and what the scatter cost on each
+            # (mi3d/field_ops.py: the emit's time depends on the arena's physical placement, 44.5-55.3 ms for one call)
+            "scatter_arena_placement": list(field_ops_mod.PLACEMENT_LOG),
             # shader clock / board power / temperature sampled on a background thread during the timed region (ClockSampler)
             "clocks": info.get("clocks"),
         }

@@ -44,7 +44,10 @@
 #endif
 // TIMING ONLY (variant builds for tools/mlp_ab.py --timing-only; the gradients are wrong with either bit): what a group of
 // the backward's vector instructions costs - 1 = no bias-gradient sums (40 dot products per tile), 2 = no ReLU masks on
-// the gradients (64 packed operations per tile)
+// the gradients (64 packed operations per tile); 4 (round 6) = recompute + input gradient ONLY, in the
+// "lane = sample" orientation throughout (14 matrix products per tile, no transposes, no weight-gradient registers) at
+// THREE waves per SIMD: what a producer wave of a producer / consumer pair could at best cost (the input-gradient planes
+// of this build are correct, every weight gradient is zero)
 #ifndef MI3D_MLP_DO_LDS
 // the 4-wide output gradient's tile turned round through the wave's LDS like every other binary16 tile, instead of on the
 // matrix core (VERDICT r04 item 3 / DESIGN.md 7.3a): 42 MFMAs and 72 packed converts per tile instead of 43 / 80.  Both
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_fwd_g(const float
 }
 
 template <class P, int NTH, int LAYERS, bool HP, bool FULL>   // FULL: dim_in = 32 (plane indices and store guards constant)
-__global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float *__restrict__ x, uint32_t x_planes,
+__global__ __launch_bounds__(kWave *kWavesPerWG, (MI3D_MLP_BWD_TIMING_CUT & 4) ? 3 : 2) void k_mlp_bwd_g(const float *__restrict__ x, uint32_t x_planes,
                                                                         const float *__restrict__ dout, uint32_t n,
                                                                         uint32_t din, Weights w, float *__restrict__ dx,
                                                                         uint32_t dx_planes, Grads g) {
@@ -1149,6 +1152,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
         // as soon as its last orientation-1 use is over, and the hidden-1 gradient is formed directly in orientation 2,
         // where its mask (the transposed activations) already is.
         KB H1p[NTH], HL[NTH];
+        KB dgH1[(MI3D_MLP_BWD_TIMING_CUT & 4) ? NTH : 1];   // (timing cut 4: hidden 1 kept in the "lane = sample" orientation)
         {
             KB H1[NTH];
 #pragma unroll
@@ -1156,6 +1160,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
                 f32x16 acc = bias(t);
                 P::mma(acc, blk(B::W1 + t), X);
                 H1[t] = P::relu(acc);
+                if constexpr ((MI3D_MLP_BWD_TIMING_CUT & 4) != 0) dgH1[t] = H1[t];
             }
             if constexpr (LAYERS == 3) {
 #pragma unroll
@@ -1169,8 +1174,10 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) HL[t] = H1[t];
             }
+            if constexpr ((MI3D_MLP_BWD_TIMING_CUT & 4) == 0) {
 #pragma unroll
             for (int t = 0; t < NTH; ++t) H1p[t] = transpose(H1[t], B::IDD);  // lane = hidden-1 feature, values = samples
+            }
         }
         // ---- gradient wrt the last hidden layer (lane = sample); dW_last and db_last from the transposed operands
         KB dHL[NTH];
@@ -1179,6 +1186,36 @@ __global__ __launch_bounds__(kWave *kWavesPerWG, 2) void k_mlp_bwd_g(const float
             f32x16 acc = splat(0.f);
             P::mma_lo(acc, blk(B::W3T + t), dO);
             dHL[t] = (MI3D_MLP_BWD_TIMING_CUT & 2) ? P::cast(acc) : P::masked(acc, HL[t]);
+        }
+        if constexpr ((MI3D_MLP_BWD_TIMING_CUT & 4) != 0) {
+            // recompute + dgrad only: dH1 = relu'(H1) (W2^T dH2) with the W2T block as the A operand (rows = hidden-1
+            // feature, lane = sample - the layout H1 has), then dX = W1^T dH1
+            if constexpr (late_prefetch) prefetch();
+            f32x16 accx = splat(0.f);
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                KB dH1;
+                if constexpr (LAYERS == 3) {
+                    f32x16 acc = splat(0.f);
+#pragma unroll
+                    for (int tk = 0; tk < NTH; ++tk) P::mma(acc, blk(B::W2T + t * NTH + tk), dHL[tk]);
+                    dH1 = P::masked(acc, dgH1[t]);
+                } else {
+                    dH1 = dHL[t];
+                }
+                P::mma(accx, blk(B::W1T + t), dH1);
+            }
+            if constexpr (HP) {
+                if (valid) {
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(dx) + row + (size_t)(2 * h) * dxp;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dst[(size_t)(4 * c) * dxp] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){accx[4 * c], accx[4 * c + 1]}, half2v));
+                        dst[(size_t)(4 * c + 1) * dxp] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){accx[4 * c + 2], accx[4 * c + 3]}, half2v));
+                    }
+                }
+            }
+            continue;
         }
         {
             KB dOp;   // lane = output index, values = the tile's samples
@@ -1587,7 +1624,7 @@ int mi3d_mlp_backward(const void *xv, uint32_t x_plane_rows, int planes_half, co
     const Weights w{W1, b1, W2, b2, W3, b3};
     const Grads g{dW1, db1, dW2, db2, dW3, db3};
     const int nth = (int)dim_hidden / 32;
-    const dim3 grid(grid_for(n, MI3D_TUNE(MI3D_T_MLP_WGS_PER_CU, 2))), block(kWave * kWavesPerWG);
+    const dim3 grid(grid_for(n, MI3D_TUNE(MI3D_T_MLP_WGS_PER_CU, (MI3D_MLP_BWD_TIMING_CUT & 4) ? 3 : 2))), block(kWave * kWavesPerWG);
     hipStream_t st = as_stream(stream);
     const bool classic = nth == 2 && layers == 3 && dim_in == (uint32_t)DIN;
 #ifdef MI3D_DEV

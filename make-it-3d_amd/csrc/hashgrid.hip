@@ -1133,6 +1133,20 @@ constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFF
 // 50.74-50.78 ms, real census 43.01-43.03 -> 40.67-40.77; same gradient (1.7e-8 x max: the order of the float atomics).
 #define MI3D_DYN_IDX 1
 #endif
+#ifndef MI3D_EMIT_ORDER_DEFAULT
+// bit 0 = the fine role walks its (tile, level) pairs level-major (see k_bin_emit); 0 = tile-major, the product's order
+#define MI3D_EMIT_ORDER_DEFAULT 0
+#endif
+#ifndef MI3D_TIMING_FAKE_PASS1
+// TIMING ONLY (round 6; a variant build for tools/scatter_ab_libs.py - the gradient is garbage):
+// the fine role's pass 1 without its position / cell / hash arithmetic.  What the forward gather could hand over in an index
+// plane (item 1a: entry, the y / z hash differences, three fractions - 16 bytes per (evaluation, fine level)) or a delta
+// hash could shorten (1b) is exactly this arithmetic: point_of (~10 vector instructions), three grid_cell (12), two
+// quarter-rate 32-bit multiplies (8 issue slots), the +1 bases and the flip (9).  Here it is replaced by what UNPACKING such
+// a plane would cost (a few shifts, masks and three converts) on bits that are already in registers - i.e. the index plane
+// with its loads for free: an upper bound of what either idea can buy.  Result: profiles/scatter_ab_libs_r06_fake_pass1.json.
+#define MI3D_TIMING_FAKE_PASS1 0
+#endif
 #ifndef MI3D_MASK_FMA
 // the coarse role's register sums by fused multiply-add with a 0 / 1 lane mask instead of select + add.  Round 5: in the
 // tools build (both forms behind a run-time switch, profiles/kbench_r05_scatter_mask_fma.json) real census 36.55-37.09 ->
@@ -1554,19 +1568,33 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                         if (!HP && p == 0u) { d.x += ex0x; d.y += ex0y; }   // (uniform; fp32 planes: summed in place)
                         const bool has = valid && p < Pf && (d.x != 0.f || d.y != 0.f);
                         const bool finite = fabsf(d.x) <= 3.4028234663852886e38f && fabsf(d.y) <= 3.4028234663852886e38f;
+#if MI3D_TIMING_FAKE_PASS1   // TIMING ONLY (see the switch's comment above k_bin_emit): no position, no cells, no hash
+                        uint32_t cy = 0, cz = 0;
+                        const uint32_t fk = r0 ^ (r0 >> 9) ^ (s << 7) ^ (p * 0x51ED27u);
+                        ccx[c] = fk >> 13;
+                        cfx[c] = (float)(fk & 1023u) * (1.0f / 1024.0f);
+                        cfy[c] = (float)((fk >> 10) & 1023u) * (1.0f / 1024.0f);
+                        cfz[c] = (float)((fk >> 20) & 1023u) * (1.0f / 1024.0f);
+#else
                         float q[3];
                         point_of(ps, base, p < ps.P ? p : 0u, q);
                         uint32_t cy, cz;
                         grid_cell(q[0], L.scale, ccx[c], cfx[c]);
                         grid_cell(q[1], L.scale, cy, cfy[c]);
                         grid_cell(q[2], L.scale, cz, cfz[c]);
+#endif
                         cd0[c] = d.x; cd1[c] = d.y;
                         const bool ok = has && finite;
                         if (ok) lmax = fmaxf(lmax, fmaxf(fabsf(d.x), fabsf(d.y)));
                         uint32_t e1s[4], pm = 0u;
                         if (L.hashed) {  // e(x + 1) = e(x) ^ flip, flip = the bits a +1 carry changes in cx (x enters with prime 1)
+#if MI3D_TIMING_FAKE_PASS1
+                            (void)cy; (void)cz;
+                            const uint32_t yz[4] = {fk, fk ^ 0x2F3A5u, fk ^ 0x5C1B3u, fk ^ 0x73216u};
+#else
                             const uint32_t hy = cy * kPrimeY, hz = cz * kPrimeZ, hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
                             const uint32_t yz[4] = {hy ^ hz, hy1 ^ hz, hy ^ hz1, hy1 ^ hz1};
+#endif
                             const uint32_t flip = (ccx[c] ^ (ccx[c] + 1u)) & mask;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) { ce0[c][j] = (ccx[c] ^ yz[j]) & mask; e1s[j] = ce0[c][j] ^ flip; }
@@ -2409,7 +2437,7 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
     coarse_mask &= dev_mask;
     const uint32_t fine_waves = fine_mask ? plan.level_waves[__builtin_ctz(fine_mask)] : 0u;
     const uint32_t coarse_waves = coarse_mask ? plan.level_waves[__builtin_ctz(coarse_mask)] : 0u;
-    const uint32_t emit_order = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_ORDER, 0);
+    const uint32_t emit_order = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_ORDER, MI3D_EMIT_ORDER_DEFAULT);
     for (uint64_t s0 = 0; s0 < n; s0 += n_slice) {
         const uint32_t s1 = (uint32_t)((s0 + n_slice < n) ? s0 + n_slice : n);
         if (fine_waves + coarse_waves)

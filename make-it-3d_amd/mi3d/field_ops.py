@@ -30,26 +30,99 @@ from . import mlp_ops
 WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56")) * (1 << 30))
 
 
-def scatter_workspace(device, needed, cap=None):
-    """uint8 scratch of min(needed, cap, 80 % of what the device can still give) bytes from torch's caching allocator.
-    A small request is honoured as it is (a 2000-sample call needs 40 MiB and gets 40 MiB: it takes the record path like
-    a large one); only after an allocation FAILURE is the request halved, and below 64 MiB of a failed request nothing
-    useful can be had: None, and the scatter takes its all-atomic path.  Requests above 1 GiB are whole GiB so that the
-    sample count drifting from step to step does not leave the caching allocator with a trail of slightly different
-    multi-GiB blocks."""
-    cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
-    gib = 1 << 30
-    free, _ = torch.cuda.mem_get_info(device)
-    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # torch can re-use this itself
-    want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(0.8 * (free + cached)))
+# ---- where the record arena LIES matters (round 6, DESIGN.md 3.2: "the placement of the arena") -------------------------
+# The emit appends to ~885 000 open (wave, bin) regions at once; what leaves the L2s is a stream of partial 64-byte
+# writes, and how well HBM takes that stream depends on the PHYSICAL placement of the arena: the same call, same data,
+# same clocks, took 44.5 to 55.3 ms on differently placed 56 GiB blocks of one process (k_bin_emit 13.7 to 18.7 ms per
+# slice, k_bin_reduce - streaming reads - 8.9 ms on all of them; TCC_EA0_WRREQ_STALL 205 M against 320 M, address
+# translation misses and plain fill / read bandwidth equal: profiles/scatter_placement_r06.json).  That was the
+# "bimodal" dense call of round 5 and most of the step-time spread between boxes: torch's caching allocator hands the arena
+# back and re-allocates it as memory pressure comes and goes, and every re-allocation is a new draw.
+# So an arena of PLACED_MIN_BYTES and more is allocated ONCE per device, kept for the life of the process (never returned
+# to the caching allocator: torch.cuda.empty_cache() does not move it; release_scatter_arena() does), and chosen: up to
+# PLACEMENT_TRIALS candidate blocks are allocated side by side, the caller's own scatter is timed on each with synthetic
+# dense gradients, the fastest is kept and the others are returned to the driver (~1 s, once).
+PLACED_MIN_BYTES = 8 << 30
+PLACEMENT_TRIALS = int(os.environ.get("MI3D_SCATTER_PLACEMENT_TRIALS", "4"))   # 1 = take the first block as it comes
+_ARENAS = {}          # device index -> the persistent arena (uint8 tensor)
+_ARENA_LAST_USE = {}  # device index -> event behind the last scatter that used it (torch's allocator no longer orders them)
+PLACEMENT_LOG = []    # one record per calibration: candidates' ms, the one kept (bench.py reports it)
+
+
+def release_scatter_arena(device=None):
+    """Give the persistent record arena(s) back to the caching allocator (the next large scatter places a new one)."""
+    for k in [k for k in _ARENAS if device is None or k == torch.device(device).index]:
+        del _ARENAS[k]
+
+
+def _alloc(want):
+    """torch.empty(want) bytes on the current device; halved after a failure, None below 64 MiB of a failed request."""
     failed = False
     while want > 0 and not (failed and want < (64 << 20)):
         try:
-            return torch.empty(want, dtype=torch.uint8, device=device)
+            return torch.empty(want, dtype=torch.uint8, device="cuda")
         except torch.cuda.OutOfMemoryError:
             failed = True
             want //= 2
     return None
+
+
+def scatter_workspace(device, needed, cap=None, trial=None):
+    """uint8 scratch of min(needed, cap, 80 % of what the device can still give) bytes.  A small request is honoured as it
+    is from torch's caching allocator (a 2000-sample call needs 40 MiB and gets 40 MiB: it takes the record path like a
+    large one); only after an allocation FAILURE is the request halved, and below 64 MiB of a failed request nothing
+    useful can be had: None, and the scatter takes its all-atomic path.  Requests above 1 GiB are whole GiB.  Requests of
+    PLACED_MIN_BYTES and more are served from the device's persistent, placed arena (see above); `trial(ws)` - optional -
+    runs the caller's scatter on a candidate block for the placement choice."""
+    cap = WORKSPACE_CAP_BYTES if cap is None else int(cap)
+    gib = 1 << 30
+    device = torch.device(device)
+    held = _ARENAS.get(device.index)
+    free, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # torch can re-use this itself
+    room = free + cached + (held.numel() if held is not None else 0)
+    want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(0.8 * room))
+    with torch.cuda.device(device):
+        if want < PLACED_MIN_BYTES:
+            return _alloc(want)
+        if held is not None and held.numel() >= want:
+            return held[:want]
+        if held is not None:                       # a larger one is needed: the old one goes first
+            del _ARENAS[device.index], held
+        n_try = 1
+        if trial is not None and PLACEMENT_TRIALS > 1:
+            torch.cuda.empty_cache()               # (cached blocks would only shrink the room for candidates)
+            free, _ = torch.cuda.mem_get_info(device)
+            n_try = max(1, min(PLACEMENT_TRIALS, int(0.9 * free) // want))
+        cands, times = [], []
+        for _ in range(n_try):
+            c = _alloc(want)
+            if c is None or (cands and c.numel() < cands[0].numel()):
+                break
+            cands.append(c)
+        if not cands:
+            return None
+        if len(cands) > 1:
+            for c in cands:
+                trial(c)                            # (warm: first touch of the block)
+                torch.cuda.synchronize(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                trial(c)
+                e1.record()
+                torch.cuda.synchronize(device)
+                times.append(e0.elapsed_time(e1))
+            best = min(range(len(cands)), key=lambda i: times[i])
+            PLACEMENT_LOG.append({"device": device.index, "bytes": cands[0].numel(), "candidates_ms": [round(t, 2) for t in times],
+                                  "kept": best})
+            keep = cands[best]
+            del cands, c
+            _ARENAS[device.index] = keep
+            torch.cuda.empty_cache()               # the others go back to the driver, not into torch's cache
+        else:
+            _ARENAS[device.index] = cands[0]
+        held = _ARENAS[device.index]
+        return held[:want] if held.numel() >= want else held
 
 
 def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, workspace_bytes=None, extra0=None):
@@ -67,20 +140,46 @@ def scatter_binned(x, x2, offsets, P0, bound, dplanes, cfg, step, n_params, work
         raise L.Mi3dError(f"extra0 must be contiguous {dplanes.dtype} planes [L={cfg['n_levels']}][{n}][2] on the same GPU")
     grad = torch.zeros(n_params, dtype=torch.float32, device=x.device)
     lib = L.lib()
-    ws, ws_bytes = None, 0
+
+    def launch(ws, planes, out):
+        L.call("mi3d_grid_scatter_binned_plus", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(planes),
+               L.ptr(extra0), int(dplanes.dtype == torch.float16), cfg["n_levels"], cfg["base_resolution"],
+               cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
+               L.ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), L.ptr(out), L.stream(x))
+
+    st = {}   # (not an attribute of `trial`: a function that names itself is a reference cycle - it would keep the gradient
+              #  planes and the arena view alive until the cyclic collector runs)
+
+    def trial(cand):
+        """This very scatter on a candidate block, with synthetic dense gradients (the real ones may be full of inf / NaN
+        while the loss scale settles - those bypass the records) into a scratch gradient."""
+        if "planes" not in st:
+            st["planes"] = torch.empty_like(dplanes).uniform_(-1.0, 1.0)
+            st["out"] = torch.zeros_like(grad)
+        with L.on(x):
+            launch(cand, st["planes"], st["out"])
+
+    ws = None
     if workspace_bytes != 0 and n > 0:
         needed = lib.mi3d_grid_scatter_binned_workspace(n, P, float(bound), float(step), cfg["n_levels"],
                                                         cfg["base_resolution"], cfg["per_level_scale"],
                                                         cfg["log2_hashmap_size"])
         if needed:
-            ws = scatter_workspace(x.device, needed, workspace_bytes)
-        ws_bytes = ws.numel() if ws is not None else 0
+            try:
+                ws = scatter_workspace(x.device, needed, workspace_bytes, trial=trial)
+            except TypeError:     # (a spy with the three-argument signature: tests/conftest.py)
+                ws = scatter_workspace(x.device, needed, workspace_bytes)
+        st.clear()
     with L.on(x):
-        grid_ops._timed("scatter", lambda: L.call(
-            "mi3d_grid_scatter_binned_plus", L.ptr(x), L.ptr(x2), n, offs_p, int(P0), P, float(bound), L.ptr(dplanes),
-            L.ptr(extra0), int(dplanes.dtype == torch.float16), cfg["n_levels"], cfg["base_resolution"],
-            cfg["per_level_scale"], cfg["log2_hashmap_size"], float(step),
-            L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(grad), L.stream(x)), n * P)
+        placed = ws is not None and ws.numel() >= PLACED_MIN_BYTES
+        if placed:   # the persistent arena is shared by every large scatter of the device: order them across streams
+            cur = torch.cuda.current_stream(x.device)
+            last = _ARENA_LAST_USE.get(x.device.index)
+            if last is not None:
+                cur.wait_event(last)
+        grid_ops._timed("scatter", lambda: launch(ws, dplanes, grad), n * P)
+        if placed:
+            _ARENA_LAST_USE[x.device.index] = cur.record_event()
     return grad
 
 

@@ -375,10 +375,10 @@ def test_compact_budget_rounds_kernels_against_oracle(cuda, oracle):
                                                ws, dep, img, nrm, 1e-2)
         a_g = alive[:n_alive].cpu().numpy()
         assert np.array_equal(a_g >= 0, alive_r >= 0)                                            # the death rule
-        np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(nrm.cpu().numpy(), nrm_r, rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=RTOL, atol=1e-6)     # (__expf on the device, expf in the oracle)
+        np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(nrm.cpu().numpy(), nrm_r, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=RTOL, atol=1e-5)
         keep = alive_r >= 0
         # the restart: the march's own t for a survivor; the reference's running sum agrees to float rounding
         t_g = t.cpu().numpy()
