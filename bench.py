@@ -87,7 +87,7 @@ def pmc_traffic(kernel, workload, evals):
     """(HBM bytes per launch, the file they come from) of `kernel`: the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
     scaled to this run's evaluation count; (None, None) if not collected."""
-    for name in ("pmc_r05.json", "pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
+    for name in ("pmc_r06.json", "pmc_r05.json", "pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel][workload]
             return rec["hbm_bytes_per_eval"] * evals, "profiles/" + name

@@ -1133,6 +1133,15 @@ constexpr uint32_t kMergeSlots = 512, kMergeProbes = 16, kMergeEmpty = 0xFFFFFFF
 // 50.74-50.78 ms, real census 43.01-43.03 -> 40.67-40.77; same gradient (1.7e-8 x max: the order of the float atomics).
 #define MI3D_DYN_IDX 1
 #endif
+#ifndef MI3D_TIMING_SEQ_FLUSH
+// TIMING ONLY (round 6; the reduce then reads garbage): the fine role's flush stores a chunk's 512 sorted records as one
+// contiguous 6 KB page of the wave's region instead of ~64 runs of ~8 records at the 64 bins' append points - the store
+// pattern a page-structured arena would have.  What leaves the L2s today is 740 M partial 64-byte write requests for 1.72 G
+// records per slice launch, and how well HBM takes them depends on where the arena lies (13.7-18.7 ms per slice,
+// profiles/scatter_placement_r06.json); this build says what the emit costs when its stores are perfectly sequential, i.e.
+// the most ANY re-organisation of the stores could buy.  Result: profiles/scatter_ab_libs_r06_seq_flush.json.
+#define MI3D_TIMING_SEQ_FLUSH 0
+#endif
 #ifndef MI3D_EMIT_ORDER_DEFAULT
 // bit 0 = the fine role walks its (tile, level) pairs level-major (see k_bin_emit); 0 = tile-major, the product's order
 #define MI3D_EMIT_ORDER_DEFAULT 0
@@ -1693,7 +1702,11 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     for (uint32_t i = lane; i < total; i += kWave) {
                         const uint4 rec = stage[i];
                         if (HP) {
+#if MI3D_TIMING_SEQ_FLUSH   // TIMING ONLY: the chunk's sorted records leave as ONE contiguous 6 KB page (see the switch's comment)
+                            const uint32_t bin = rec.w, at = (ti * 7u + (p0 >> 1)) * 512u + i + 0u * gdelta[bin];
+#else
                             const uint32_t bin = rec.w, at = i + gdelta[bin];   // = bin * cap + slot
+#endif
                             if (all_fit) {
 #ifdef MI3D_DEV
                                 if (!(fine_level_major & 0x800u))

@@ -416,3 +416,51 @@ def test_binned_scatter_with_hash_tables_smaller_than_a_bin(cuda, oracle, half, 
     for l in range(16):   # per level: a misplaced partner shows on its own level, whatever the others' magnitudes are
         a, b = int(cfg.offsets[l]) * 2, int(cfg.offsets[l + 1]) * 2
         assert np.abs(g[a:b] - ref[a:b]).max() <= 5e-5 * np.abs(ref[a:b]).max() + 1e-6, l
+
+
+def test_large_scatters_share_one_persistent_placed_arena(cuda, oracle, monkeypatch):
+    """mi3d.field_ops keeps ONE record arena per device for requests of PLACED_MIN_BYTES and more and chooses it among
+    candidate blocks by timing the caller's own scatter on each (the emit's time depends on the arena's
+    physical placement).  With the threshold lowered to this test's size: the calibration runs once (candidates timed,
+    one kept, logged), later calls are served from the same block - also smaller ones, as a prefix - the gradient is what
+    a per-call allocation gives, a larger request replaces the arena, release_scatter_arena() lets go of it."""
+    from mi3d import field_ops, grid_ops
+    rng = np.random.default_rng(23)
+    cfg = oracle.GridConfig()
+    kcfg = dict(n_levels=cfg.n_levels, base_resolution=cfg.base_resolution, per_level_scale=cfg.per_level_scale,
+                log2_hashmap_size=cfg.log2_hashmap_size)
+    n = 4000
+    x = _ray_like_points(rng, n, 1.0)
+    x2 = (x + rng.normal(size=x.shape).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    offs, P0 = grid_ops.stencil_offsets(center=True, second=True)
+    P = offs.shape[0]
+    planes = rng.normal(size=(16, P * n, 2)).astype(np.float16)
+    args = (T(x, cuda), T(x2, cuda), offs, P0, 1.0, T(planes, cuda), kcfg, 0.0034, cfg.n_params)
+    field_ops.release_scatter_arena()
+    want = field_ops.scatter_binned(*args).cpu().numpy()               # per-call allocation (below the threshold)
+    assert not field_ops._ARENAS
+    monkeypatch.setattr(field_ops, "PLACED_MIN_BYTES", 1 << 20)
+    monkeypatch.setattr(field_ops, "PLACEMENT_TRIALS", 3)
+    log0 = len(field_ops.PLACEMENT_LOG)
+    try:
+        got = field_ops.scatter_binned(*args).cpu().numpy()
+        assert len(field_ops.PLACEMENT_LOG) == log0 + 1
+        rec = field_ops.PLACEMENT_LOG[-1]
+        assert len(rec["candidates_ms"]) == 3 and 0 <= rec["kept"] < 3 and all(t > 0 for t in rec["candidates_ms"])
+        arena = field_ops._ARENAS[cuda.index]
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-6 * scale               # (the order of the table's float atomics)
+        again = field_ops.scatter_binned(*args).cpu().numpy()
+        assert field_ops._ARENAS[cuda.index] is arena and len(field_ops.PLACEMENT_LOG) == log0 + 1
+        assert np.abs(again - want).max() <= 2e-6 * scale
+        # a smaller request is a prefix of the same block; a larger one replaces it
+        m = 2500
+        small = (T(x[:m], cuda), T(x2[:m], cuda), offs, P0, 1.0,
+                 T(np.ascontiguousarray(planes.reshape(16, P, n, 2)[:, :, :m].reshape(16, P * m, 2)), cuda), kcfg, 0.0034, cfg.n_params)
+        field_ops.scatter_binned(*small)
+        assert field_ops._ARENAS[cuda.index] is arena
+        ws = field_ops.scatter_workspace(cuda, arena.numel() + (1 << 20))
+        assert ws.numel() == arena.numel() + (1 << 20) and field_ops._ARENAS[cuda.index] is not arena
+    finally:
+        field_ops.release_scatter_arena()
+    assert not field_ops._ARENAS
