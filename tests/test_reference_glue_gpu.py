@@ -8,6 +8,8 @@ This pins the glue the kernels sit under - run_cuda's training branch with both 
 parameter gradient, update_extra_state's grid values / EMA / mean / bitfield, and the eval march-composite loop - on
 the reference itself rather than on a restatement of it.  fp32 (no autocast): 1e-4 relative, as BASELINE.json states;
 one autocast case checks the route under AMP the way main.py runs it."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -219,3 +221,55 @@ def test_eval_render_matches_the_reference(ref, cuda):
         _close(b[k], a[k], what=k)
     # the normal map is a weighted sum of ratios of finite differences: compare in absolute terms
     _close(b["normal"], a["normal"], rtol=0, atol=2e-3, what="normal")
+
+
+def test_main_py_import_line_trains_on_the_fused_field(ref, cuda):
+    """INTEGRATION.md section 2, on the GPU, in a fresh interpreter whose PYTHONPATH starts with make-it-3d_amd/autopatch (the
+    zero-edit route): `from nerf.network_tcnn import NeRFNetwork` (main.py:104) hands out mi3d.network.NeRFNetwork, a
+    training render + both backward passes of the reference schedule run on it (13-point fused field: ONE binned scatter
+    call for the two passes), and its outputs equal the reference's own class on the same weights (1e-4)."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import PKG, ROOT
+    script = """
+        import sys, torch
+        from oracle import ref_import
+        ref_import.install()
+        from nerf.network_tcnn import NeRFNetwork            # main.py:104
+        import mi3d.network, nerf.network_tcnn as m
+        from mi3d import field_ops, rays as R, sds_step
+        assert NeRFNetwork is mi3d.network.NeRFNetwork
+        dev = torch.device("cuda:0")
+        opt = ref_import.default_opt(cuda_ray=True, lambda_smooth=1.0, max_steps=256)
+        torch.manual_seed(0)
+        ours = NeRFNetwork(opt).to(dev)
+        with torch.no_grad():
+            ours.encoder.params.uniform_(-0.3, 0.3)
+        theirs = m.NeRFNetwork_reference(opt).to(dev)
+        theirs.load_state_dict(ours.state_dict())
+        for net in (ours, theirs):
+            sds_step.set_bitfield(net, 0.5)
+        ro, rd, ds = R.view_rays(32, 32, device=dev)
+        outs, calls = [], []
+        real = field_ops.scatter_binned
+        field_ops.scatter_binned = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        for net in (theirs, ours):
+            net.train()
+            calls.clear()
+            torch.manual_seed(3)
+            out = net.render(ro, rd, depth_scale=ds, bg_color=torch.full((3,), 0.7, device=dev), perturb=True,
+                             ambient_ratio=1.0, shading="albedo", force_all_rays=True, dt_gamma=0, max_steps=256)
+            out["image"].backward(torch.full_like(out["image"], 1e-3), retain_graph=True)     # nerf/sd.py:171
+            (out["loss_orient"] + out["weights_sum"].mean()).backward()                         # nerf/utils.py:983
+            assert net.encoder.params.grad.abs().sum() > 0
+            outs.append(out)
+        assert len(calls) == 1, calls      # the fused class: the first pass's point-0 planes rode along in ONE scatter
+        for k in ("image", "depth", "weights_sum"):
+            torch.testing.assert_close(outs[1][k], outs[0][k], rtol=1e-4, atol=1e-6)
+        print("ok")
+    """
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(PKG, "autopatch"), PKG, ROOT])
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
