@@ -989,6 +989,17 @@ struct BinPlan {
     uint32_t n_levels, n_bins;
 };
 
+#ifndef MI3D_LEVEL_PAD_BYTES
+// Padding behind every fine (pair-record) level's block of the arena.  At C2 the nine fine levels' blocks are 4.319 GB each,
+// i.e. 4 GiB + 24 MB: the regions a wave appends to at the same time - same (wave, bin), nine levels - lie almost exactly
+// 4 GiB apart, and the emit's time turned out to depend on the arena's PHYSICAL base with a period of 4 GiB (a block whose
+// base is shifted by 2 GiB mod 4 GiB: 56.0 ms instead of 48.0, profiles/scatter_placement_r06.json `shift`).  See
+// Measured (tools/scatter_bimodal.py --shift --libs, profiles/scatter_placement_r06.json
+// `shift_pads`): paddings of 64 MiB / 455 MiB / 1100 MiB move the pattern (1100 MiB: 46.0 ms where the product takes 48.2 - and
+// 48.5 where it takes 46.7) but every variant still swings with the placement (53.5 against 54.5 on the worst block): the
+// padding is NOT the fix; 0 stays.
+#define MI3D_LEVEL_PAD_BYTES 0
+#endif
 __host__ __device__ inline uint32_t level_bins(const GridLevel &L) { return (L.size + kBinEntries - 1) / kBinEntries; }
 
 inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
@@ -1042,6 +1053,7 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         p.total_bytes += (uint64_t)p.level_waves[l] * bins * p.level_cap[l] *
                          (row ? (p.rec12 ? sizeof(Row12) : sizeof(RowRecord)) : sizeof(BinRecord));
         p.total_bytes = (p.total_bytes + 255u) / 256u * 256u;
+        if (row) p.total_bytes += (uint64_t)MI3D_LEVEL_PAD_BYTES;   // (see MI3D_LEVEL_PAD_BYTES)
         p.total_counts += p.level_waves[l] * bins;
         p.total_max += p.level_waves[l];
     }

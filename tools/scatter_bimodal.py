@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--arenas", action="store_true", help="explicitly held arenas before / after SD steps, re-allocated, fragmented")
     ap.add_argument("--placements", type=int, default=0, help="that many freshly allocated arenas, every --libs build on each")
     ap.add_argument("--libs", default="make-it-3d_amd/csrc/libmi3d.so")
+    ap.add_argument("--shift", type=int, default=0, help="that many spacer sizes (k x --shift-gib) in front of a fresh arena")
+    ap.add_argument("--shift-gib", type=float, default=6.0)
     ap.add_argument("--recipes", action="store_true", help="allocator conditionings before the arena is allocated")
     ap.add_argument("--matrix", action="store_true", help="with / without / zero deferred pair, before and after SD stand-in steps")
     ap.add_argument("--out", default="gpurun_out/scatter_bimodal.json")
@@ -225,6 +227,50 @@ def main():
             print(rec)
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         json.dump({"samples": n, "libs": paths, "placements": rows}, open(a.out, "w"), indent=1)
+        return
+    if a.shift:
+        # Can better placements be FOUND by shifting where the arena lands - a spacer of k x `--shift-gib` GiB allocated just
+        # before it - instead of holding several 56 GiB candidates side by side?
+        real_alloc = real_ws
+        held = {}
+
+        def ws(device, needed, cap=None):
+            if "a" not in held:
+                held["a"] = real_alloc(device, needed, cap)
+            return held["a"]
+        field_ops.scatter_workspace = ws
+        field_ops.PLACED_MIN_BYTES = 1 << 62     # (plain per-call path: this tool holds the arena itself)
+
+        def one():
+            call = lambda: field_ops.scatter_binned(xs, xs2, offs, P0, 1.0, g_dense, cfg, step, 12196240)   # noqa: E731
+            call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call(); call(); call()
+            e1.record()
+            torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) / 3, 2)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import scatter_ab_libs
+        paths = a.libs.split(",")
+        libs = [scatter_ab_libs.load(p_) for p_ in paths]
+        rows = []
+        for rep in range(2):
+            for k in range(a.shift):
+                held.clear()
+                torch.cuda.empty_cache()
+                spacer = torch.empty(int(k * a.shift_gib * 2 ** 30) or 1, dtype=torch.uint8, device=dev)
+                rec = {"rep": rep, "spacer_GiB": k * a.shift_gib}
+                for p_, lib in zip(paths, libs):
+                    L._lib = lib
+                    rec[os.path.basename(p_)] = one()
+                rec["arena_ptr"] = held["a"].data_ptr()
+                rows.append(rec)
+                print(rec, flush=True)
+                del spacer
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        json.dump({"samples": n, "shift": rows}, open(a.out, "w"), indent=1)
         return
     if a.recipes:
         # Round 6, call 5: a re-allocated arena is fast (47.9 ms), slow (55.3) - or, allocated while 12.5 GiB of 64 MiB blocks
