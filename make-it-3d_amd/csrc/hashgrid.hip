@@ -277,12 +277,37 @@ __host__ __device__ __forceinline__ LevelFast level_fast(const GridLevel &L, int
 }
 struct __attribute__((packed, aligned(8))) EntryPair { float ax, ay, bx, by; };  // entries e, e + 1 of a level
 
+#ifndef MI3D_MUL24
+// Tried in round 6 and NOT taken (0): 24-bit multiplies in the emit.  The emit is bound by vector-instruction issue, and a
+// 32-bit integer multiply (v_mul_lo_u32) was assumed to hold the issue port four times as long as v_mul_u32_u24.  (1) The
+// gather table's slot hash - eight multiplies per table pass, ~40 per (tile, level) of the coarse role - by one 24-bit
+// product; (2) the spatial hash's c * prime (needed exactly mod 2^32) as two signed 24-bit products of the prime's halves,
+// c * (prime & 0x7FFFFF) + ((c * (prime >> 23)) << 23), three instructions.  Same entries, same gradient (7e-8 x max: the order
+// of the table's float atomics).  Product-grade builds in one process on one arena, four interleaved rounds
+// (profiles/scatter_ab_libs_r06_mul24.json): dense 49.83 -> 50.05 ms, real census 39.79 -> 40.28: slightly SLOWER - the 32-bit
+// multiplies are not what the issue port waits for (consistent with MI3D_TIMING_FAKE_PASS1's small ceiling).
+#define MI3D_MUL24 0
+#endif
+__device__ __forceinline__ uint32_t mul_prime(uint32_t c, uint32_t prime, bool c_fits_24) {
+    // (SIGNED 24-bit products with the prime split at bit 23: a coordinate may be base - 1 = 0xFFFFFFFF at the box's lower
+    //  face, and -1 * prime mod 2^32 comes out right this way; `c_fits_24` - uniform - says every coordinate of the level
+    //  lies in [-2^23, 2^23))
+    if (MI3D_MUL24 != 0 && c_fits_24)
+        return (uint32_t)__mul24((int)c, (int)(prime & 0x7FFFFFu)) + ((uint32_t)__mul24((int)c, (int)(prime >> 23)) << 23);
+    return c * prime;
+}
+__device__ __forceinline__ uint32_t merge_slot(uint32_t e) {   // 9-bit slot of the per-wave gather table (kMergeSlots = 512)
+    if (MI3D_MUL24 != 0) return (__umul24(e, 0x9E3779u) >> 14) & 511u;
+    return (e * 2654435761u) >> (32 - 9);
+}
+
 // four corner entries of a cell - the z-bit `zb` half of its eight, corner j = x-bit | y-bit << 1 - by the short routes
 // (grid_entry's values)
 __device__ __forceinline__ void corner_entries4(const GridLevel &L, const LevelFast &F, uint32_t cx, uint32_t cy,
                                                 uint32_t cz, uint32_t zb, uint32_t (&e)[4]) {
     if (F.kind == kHashPow2) {
-        const uint32_t hy = cy * kPrimeY, hz = (cz + zb) * kPrimeZ, a = hy ^ hz, b = (hy + kPrimeY) ^ hz, cx1 = cx + 1u;
+        const bool f24 = (L.res >> 22) == 0u;   // (cells <= res + 1 < 2^23)
+        const uint32_t hy = mul_prime(cy, kPrimeY, f24), hz = mul_prime(cz + zb, kPrimeZ, f24), a = hy ^ hz, b = (hy + kPrimeY) ^ hz, cx1 = cx + 1u;
         e[0] = (a ^ cx) & F.last; e[1] = (a ^ cx1) & F.last; e[2] = (b ^ cx) & F.last; e[3] = (b ^ cx1) & F.last;
         return;
     }
@@ -297,7 +322,10 @@ __device__ __forceinline__ void corner_entries4(const GridLevel &L, const LevelF
 
 // one corner's entry by the same routes
 __device__ __forceinline__ uint32_t corner_entry1(const GridLevel &L, const LevelFast &F, uint32_t x, uint32_t y, uint32_t z) {
-    if (F.kind == kHashPow2) return (x ^ (y * kPrimeY) ^ (z * kPrimeZ)) & F.last;
+    if (F.kind == kHashPow2) {
+        const bool f24 = (L.res >> 22) == 0u;   // (uniform; the coordinates lie in [-1, res + 1])
+        return (x ^ mul_prime(y, kPrimeY, f24) ^ mul_prime(z, kPrimeZ, f24)) & F.last;
+    }
     if (F.kind == kDense3) {
         const uint32_t a = x + __umul24(y, L.res) + __umul24(z, F.res2), size = F.last + 1u;
         return min(a, a - size);
@@ -1361,7 +1389,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                     uint32_t e[4], slot[4], old[4];
                     corner_entries4(L, LF, ex, ey, ez, half, e);
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) slot[j] = (e[j] * 2654435761u) >> (32 - 9);
+                    for (uint32_t j = 0; j < 4; ++j) slot[j] = merge_slot(e[j]);
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j) {
                         const uint32_t k = 4 * half + j;
@@ -1392,7 +1420,7 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
             auto gather4 = [&](const uint32_t (&e)[4], const float (&g0)[4], const float (&g1)[4]) __attribute__((always_inline)) {
                 uint32_t slot[4], old[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) slot[j] = (e[j] * 2654435761u) >> (32 - 9);
+                for (uint32_t j = 0; j < 4; ++j) slot[j] = merge_slot(e[j]);
 #pragma unroll
                 for (uint32_t j = 0; j < 4; ++j)
                     old[j] = (g0[j] != 0.f || g1[j] != 0.f) ? atomicCAS(&keys[slot[j]], kMergeEmpty, e[j]) : e[j];
@@ -1613,7 +1641,8 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
                             (void)cy; (void)cz;
                             const uint32_t yz[4] = {fk, fk ^ 0x2F3A5u, fk ^ 0x5C1B3u, fk ^ 0x73216u};
 #else
-                            const uint32_t hy = cy * kPrimeY, hz = cz * kPrimeZ, hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
+                            const bool f24 = (L.res >> 22) == 0u;
+                            const uint32_t hy = mul_prime(cy, kPrimeY, f24), hz = mul_prime(cz, kPrimeZ, f24), hy1 = hy + kPrimeY, hz1 = hz + kPrimeZ;
                             const uint32_t yz[4] = {hy ^ hz, hy1 ^ hz, hy ^ hz1, hy1 ^ hz1};
 #endif
                             const uint32_t flip = (ccx[c] ^ (ccx[c] + 1u)) & mask;
