@@ -14,6 +14,7 @@ The per-layer composition (grid_ops.encode_points + mlp_ops.fused_mlp) stays ava
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -44,6 +45,7 @@ WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56"
 # dense gradients, the fastest is kept and the others are returned to the driver (~1 s, once).
 PLACED_MIN_BYTES = 8 << 30
 PLACEMENT_TRIALS = int(os.environ.get("MI3D_SCATTER_PLACEMENT_TRIALS", "4"))   # 1 = take the first block as it comes
+_ARENA_LOCK = threading.RLock()   # (autograd runs backward passes on worker threads, one per device)
 _ARENAS = {}          # device index -> the persistent arena (uint8 tensor)
 _ARENA_LAST_USE = {}  # device index -> event behind the last scatter that used it (torch's allocator no longer orders them)
 PLACEMENT_LOG = []    # one record per calibration: candidates' ms, the one kept (bench.py reports it)
@@ -51,8 +53,10 @@ PLACEMENT_LOG = []    # one record per calibration: candidates' ms, the one kept
 
 def release_scatter_arena(device=None):
     """Give the persistent record arena(s) back to the caching allocator (the next large scatter places a new one)."""
-    for k in [k for k in _ARENAS if device is None or k == torch.device(device).index]:
-        del _ARENAS[k]
+    with _ARENA_LOCK:
+        for k in [k for k in _ARENAS if device is None or k == torch.device(device).index]:
+            del _ARENAS[k]
+            _ARENA_LAST_USE.pop(k, None)
 
 
 def _alloc(want):
@@ -82,7 +86,7 @@ def scatter_workspace(device, needed, cap=None, trial=None):
     cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # torch can re-use this itself
     room = free + cached + (held.numel() if held is not None else 0)
     want = min((int(needed) + gib - 1) // gib * gib if needed > gib else int(needed), cap, int(0.8 * room))
-    with torch.cuda.device(device):
+    with torch.cuda.device(device), _ARENA_LOCK:
         if want < PLACED_MIN_BYTES:
             return _alloc(want)
         if held is not None and held.numel() >= want:
@@ -94,12 +98,21 @@ def scatter_workspace(device, needed, cap=None, trial=None):
             torch.cuda.empty_cache()               # (cached blocks would only shrink the room for candidates)
             free, _ = torch.cuda.mem_get_info(device)
             n_try = max(1, min(PLACEMENT_TRIALS, int(0.9 * free) // want))
-        cands, times = [], []
+        # candidates SPREAD over the free memory (a spacer in front of each): blocks allocated back to back sit next to
+        # each other, and whole stretches of the device memory are slow for this write stream - at 32 GiB the first three of
+        # six back-to-back candidates timed 61-62 ms, the next three 52-54 (profiles/bench_r06_arena_cap_curve.json)
+        gap = 0
+        if n_try > 1:
+            gap = max(0, (int(0.9 * free) - n_try * want) // n_try) >> 28 << 28
+        cands, times, spacers = [], [], []
         for _ in range(n_try):
+            if gap:
+                spacers.append(_alloc(gap))
             c = _alloc(want)
             if c is None or (cands and c.numel() < cands[0].numel()):
                 break
             cands.append(c)
+        del spacers
         if not cands:
             return None
         if len(cands) > 1:
