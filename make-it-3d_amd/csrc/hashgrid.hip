@@ -964,7 +964,10 @@ uint32_t default_merge_levels(const GridTable &T, float step01) {
 // (tools/scatter_ab_libs.py): the tools build, with every variant behind a run-time switch, allocates registers for all
 // of them.
 constexpr uint32_t kBinShift = 13, kBinEntries = 1u << kBinShift;
-constexpr uint32_t kEmitWavesMax = 1536;
+#ifndef MI3D_EMIT_FINE_WAVES_DEFAULT
+#define MI3D_EMIT_FINE_WAVES_DEFAULT 1536
+#endif
+constexpr uint32_t kEmitWavesMax = MI3D_EMIT_FINE_WAVES_DEFAULT;
 constexpr uint32_t kReduceWavesC = 16;  // waves of a reduce workgroup (= kReduceWaves below)
 
 struct __attribute__((packed, aligned(4))) BinRecord {
@@ -1015,8 +1018,22 @@ struct BinPlan {
     uint32_t n_reduce_wgs;
     uint32_t total_counts, total_max;
     uint32_t n_levels, n_bins;
+    uint32_t claim0;                        // level_max[claim0 ..+1] as uint32: the two roles' tile-claim counters (k_bin_emit)
 };
 
+#ifndef MI3D_EMIT_COARSE_WAVES_DEFAULT
+// Emitting waves of the coarse role = regions per coarse bin the reduce has to walk (a fixed cost per slice).  The chip holds
+// 3072 emitting waves at a time (256 CUs x 4 SIMDs x 3), 1536 of them the fine role's: 3072 coarse waves are two full rounds
+// of the other half.  Round 6, product-grade builds in one process on a placed arena (tools/scatter_ab_libs.py,
+// profiles/scatter_ab_libs_r06_coarse_waves_{56,30}GiB.json; dense / real census, ms): 16384 (rounds 3-5) 47.8 / 41.1,
+// 4096 48.7 / 43.3, 3072 47.1 / 40.6, 2048 53.9 / 48.3, 1536 47.0 / 40.6, 1024 55.5 / 49.3, 512 81.3 / 75.2 - whole rounds or
+// many; with four slices (30 GiB) 16384 54.4 / 44.6, 3072 51.9 / 41.8, 1536 51.7 / 41.9.
+#define MI3D_EMIT_COARSE_WAVES_DEFAULT 3072
+#endif
+#ifndef MI3D_HASHED_SLACK
+// a hashed level's region capacity over the uniform share of its records (plan_for)
+#define MI3D_HASHED_SLACK 1.25
+#endif
 #ifndef MI3D_LEVEL_PAD_BYTES
 // Padding behind every fine (pair-record) level's block of the arena.  At C2 the nine fine levels' blocks are 4.319 GB each,
 // i.e. 4 GiB + 24 MB: the regions a wave appends to at the same time - same (wave, bin), nine levels - lie almost exactly
@@ -1037,7 +1054,7 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
 }
 
 // The plan for slices of n_slice samples.  Fine levels are emitted by at most 1536 waves (the lines being appended to
-// must fit the L2s); the coarse levels' run merging is latency-bound and emits few records, so it gets up to 16384.
+// must fit the L2s); the coarse levels' run merging is latency-bound and emits few records, so it gets up to 3072 (see MI3D_EMIT_COARSE_WAVES_DEFAULT).
 // Region capacities - hashed levels: the uniform share of the UNMERGED record count plus 25 % (the hash spreads them
 // evenly).  Dense levels: bins are spatial, a wave's samples cluster in few of them, and merging thins the records by
 // an unknown factor: the share assumes a quarter of the geometric run length and two-fold imbalance.  A full region is
@@ -1045,7 +1062,7 @@ inline uint32_t round_waves(uint64_t w, uint32_t cap_waves) {
 inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float step01, uint32_t merge_levels,
                         bool half_planes = false) {
     const uint32_t fine_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_FINE_WAVES, kEmitWavesMax);
-    const uint32_t coarse_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_COARSE_WAVES, 16384);
+    const uint32_t coarse_waves = (uint32_t)MI3D_TUNE(MI3D_T_EMIT_COARSE_WAVES, MI3D_EMIT_COARSE_WAVES_DEFAULT);
     BinPlan p{};
     p.n_levels = T.n_levels;
     p.rec12 = half_planes ? 1u : 0u;
@@ -1058,7 +1075,7 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         const double pts_per_wave = (double)n_slice * P / p.level_waves[l];
         double per = pts_per_wave * 8.0 / bins;
         if (L.hashed) {
-            per *= 1.25;
+            per *= MI3D_HASHED_SLACK;
         } else {
             double run = merged ? (1.0 / (double)L.res) / (1.5 * (double)step01) / 4.0 : 1.0;
             run = run < 1.0 ? 1.0 : run;
@@ -1085,6 +1102,8 @@ inline BinPlan plan_for(const GridTable &T, uint64_t n_slice, uint32_t P, float 
         p.total_counts += p.level_waves[l] * bins;
         p.total_max += p.level_waves[l];
     }
+    p.claim0 = p.total_max;
+    p.total_max += 4u;
     return p;
 }
 // How many reduce workgroups share a bin.  A bin's records are spread over the level's emitting waves, so `split`
@@ -1118,6 +1137,22 @@ inline void plan_reduce_splits(BinPlan &p, const GridTable &T, uint32_t base_spl
 inline size_t bin_workspace_bytes(const BinPlan &p) {
     return (size_t)p.total_bytes + (size_t)p.total_counts * sizeof(uint32_t) +
            (size_t)p.total_max * sizeof(float);
+}
+
+// The slice length of a call over n samples: ceil(n / k) for the smallest k whose plan fits the workspace (k = 1, 2, 3 ...
+// up to 64, doubling from there).  Round 2-5 halved the slice (k = 1, 2, 4 ...): at C2 an arena between 31 and 46 GiB then
+// ran the four-slice plan of 24.7 GB although three slices (33 GB) fit - and every slice has a fixed cost (the emit's and
+// the reduce's tails, the regions the reduce walks).  `plan` receives the slice's plan (which may still not fit: the caller
+// checks and takes the atomic path).
+inline uint64_t slice_for(const GridTable &T, uint64_t n, uint32_t P, float step01, uint32_t merge_levels, bool half_planes,
+                          size_t workspace_bytes, BinPlan &plan) {
+    uint64_t n_slice = n;
+    plan = plan_for(T, n_slice, P, step01, merge_levels, half_planes);
+    for (uint64_t k = 2; n_slice > kWave && bin_workspace_bytes(plan) > workspace_bytes; k = k < 64 ? k + 1 : 2 * k) {
+        n_slice = (n + k - 1) / k;
+        plan = plan_for(T, n_slice, P, step01, merge_levels, half_planes);
+    }
+    return n_slice;
 }
 
 __device__ __forceinline__ void emit_record(const BinPlan &plan, const GridLevel &L, uint32_t l, uint32_t gw, uint32_t e,
@@ -1254,6 +1289,14 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     const uint32_t span = n_waves * kWave, first = s_begin + gw * kWave;
     const uint32_t nt = first < s_end ? (s_end - first + span - 1) / span : 0u;
     const bool level_major = !role_b && (fine_level_major & 1u);
+    // Tiles are CLAIMED from a per-role counter (round 6), not dealt: a tile's cost follows its non-zero gradient pairs,
+    // and with tiles dealt statically (wave gw: tiles gw, gw + n_waves ...) the launch ended when the unluckiest of its
+    // persistent waves did - the slots of all the others idle meanwhile, once per slice.  (Which wave emits a tile does
+    // not matter to the sums: the reduce adds integers.)  The dealt order stays behind bit 0x100000 of the order word.
+    const bool claim = !level_major && !(fine_level_major & 0x100000u);
+    uint32_t *claim_ctr = reinterpret_cast<uint32_t *>(level_max + plan.claim0) + (role_b ? 1 : 0);
+    const uint32_t n_tiles = (s_end - s_begin + kWave - 1) / kWave;
+    uint32_t claimed = 0;
 #ifdef MI3D_DEV  // tools build: 0x10000 = the coarse role's shared-face pass off (A/B against round 3's pair passes);
                  // 0x20000 toggles the run-merged group flush against its product default
     const bool face_on = !(fine_level_major & 0x10000u);
@@ -1269,14 +1312,24 @@ __global__ __launch_bounds__(kWave *kWaves, 3) void k_bin_emit(PointSet ps, uint
     uint32_t cur_tile = 0xFFFFFFFFu, s = 0;
     bool valid = false;
     float b00 = 0.f, b01 = 0.f, b02 = 0.f, b10 = 0.f, b11 = 0.f, b12 = 0.f;  // the tile's positions
-    for (uint32_t it = 0; it < nl * nt; ++it) {
-        const uint32_t ti = level_major ? it % nt : it / nl, li = level_major ? it / nt : it % nl;
+    for (uint32_t it = 0; claim || it < nl * nt; ++it) {
+        uint32_t ti = level_major ? it % nt : it / nl;
+        const uint32_t li = level_major ? it / nt : it % nl;
+        if (claim) {
+            if (li == 0u) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(claim_ctr, 1u);
+                claimed = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            }
+            if (claimed >= n_tiles) break;
+            ti = claimed;
+        }
         uint32_t rest = level_mask;
         for (uint32_t k = 0; k < li; ++k) rest &= rest - 1u;
         const uint32_t l = (uint32_t)__builtin_ctz(rest);  // the li-th level of the role's mask
         if (ti != cur_tile) {
             cur_tile = ti;
-            s = first + ti * span + lane;
+            s = claim ? s_begin + ti * kWave + lane : first + ti * span + lane;
             valid = s < s_end;
             float fresh[2][3];
             load_bases(ps, s, valid, fresh);
@@ -2439,14 +2492,10 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
     const uint32_t merge_levels = default_merge_levels(T, step01 * merge_steps());
     const uint32_t plane_rows = n * P;
 
-    // the slice: the largest sample count (halving from n) whose record arena fits the workspace
-    uint64_t n_slice = n;
+    // the slice: the samples are cut into the FEWEST equal slices whose record arena fits the workspace
     const uint32_t P_rec = P + ((extra0 != nullptr && dout_half) ? 1u : 0u);   // (binary16: the extra pair is a record of its own)
-    BinPlan plan = plan_for(T, n_slice, P_rec, step01, merge_levels, dout_half != 0);
-    while (n_slice > kWave && bin_workspace_bytes(plan) > workspace_bytes) {
-        n_slice = (n_slice + 1) / 2;
-        plan = plan_for(T, n_slice, P_rec, step01, merge_levels, dout_half != 0);
-    }
+    BinPlan plan;
+    const uint64_t n_slice = slice_for(T, n, P_rec, step01, merge_levels, dout_half != 0, workspace_bytes, plan);
     if (workspace == nullptr || bin_workspace_bytes(plan) > workspace_bytes) {
         // no usable workspace: the atomic kernels, with private copies of the table against same-line serialisation
         // when the caller's scratch at least holds those
@@ -2497,6 +2546,7 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
         if (fine_waves + coarse_waves)
         {
             const dim3 eg((fine_waves + coarse_waves) / kWaves), eb(kWave * kWaves);
+            (void)hipMemsetAsync(level_max + plan.claim0, 0, 4 * sizeof(uint32_t), st);   // the roles' tile-claim counters
             if (dout_half)
                 hipLaunchKernelGGL(k_bin_emit<true>, eg, eb, lds, st, ps, (uint32_t)s0, s1, dout_planes, plane_rows, n, extra0, T,
                                    plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
@@ -2557,12 +2607,8 @@ int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint
     build_grid_table(T, n_levels, base_resolution, per_level_scale, log2_hashmap_size);
     const float step01 = step > 0.f ? step / (2.0f * bound) : 1.0f / 512.0f;
     const uint32_t merge_levels = default_merge_levels(T, step01 * merge_steps());
-    uint64_t n_slice = n;  // the same halving mi3d_grid_scatter_binned does
-    BinPlan p = plan_for(T, n_slice, P, step01, merge_levels);
-    while (n_slice > kWave && bin_workspace_bytes(p) > workspace_bytes) {
-        n_slice = (n_slice + 1) / 2;
-        p = plan_for(T, n_slice, P, step01, merge_levels);
-    }
+    BinPlan p;
+    const uint64_t n_slice = slice_for(T, n, P, step01, merge_levels, false, workspace_bytes, p);  // as mi3d_grid_scatter_binned
     const uint64_t evals = n_slice * P;
     plan_reduce_splits(p, T, evals >= 30000000ull ? 4u : (evals >= 8000000ull ? 2u : 1u), merge_levels);
     out[0] = n_slice; out[1] = bin_workspace_bytes(p); out[2] = merge_levels; out[3] = p.n_reduce_wgs;

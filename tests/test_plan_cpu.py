@@ -68,9 +68,20 @@ def test_scatter_plan_c2(lib):
     assert head["merge"] == 7                                        # cells of >= 4 marching steps: levels 0-6
     assert [l["bins"] for l in lv[:6]] == [1, 2, 4, 10, 26, 64] and all(l["bins"] == 64 for l in lv[5:])
     assert [l["row"] for l in lv] == [0] * 7 + [1] * 9               # x-pair records on the fine levels only
-    # a workspace of 100 GiB: the call halves the slice until it fits
+    # a workspace of 100 GiB: the samples are cut into the FEWEST equal slices that fit (fp32 planes, 16-byte records: two)
     head2, lv2 = _scatter_plan(lib, n, P, STEP, 100 << 30)
     assert head2["n_slice"] == (n + 1) // 2 and head2["bytes"] <= 100 << 30 < need
+    # ... and not the fewest power of two (rounds 2-5 halved: where three slices fit, four ran - every slice has a fixed cost)
+    for gib in (56, 40, 31, 24, 12):
+        hk, _ = _scatter_plan(lib, n, P, STEP, gib << 30)
+        k = -(-n // hk["n_slice"])
+        assert hk["n_slice"] == -(-n // k) and hk["bytes"] <= gib << 30
+        one_fewer, _ = _scatter_plan(lib, -(-n // (k - 1)), P, STEP, 1 << 50)
+        assert one_fewer["bytes"] > gib << 30, (gib, k)
+    assert -(-n // _scatter_plan(lib, n, P, STEP, 40 << 30)[0]["n_slice"]) == 3
+    # a workspace too small for any slice: the plan of one tile comes back and does not fit (the call takes the atomic path)
+    head0, _ = _scatter_plan(lib, n, P, STEP, 1 << 20)
+    assert head0["n_slice"] <= 64 and head0["bytes"] > 1 << 20
     for l, r in enumerate(lv2):
         assert r["cap"] % 1 == 0 and r["cap"] >= 64
         assert 1 <= r["split"] <= max(1, r["waves"] // 16)            # every reduce wave gets at least one region

@@ -42,6 +42,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--out", default="gpurun_out/scatter_ab_libs.json")
+    ap.add_argument("--capture", type=int, default=0,
+                    help="N > 0: also time the libraries on the gradient planes of a REAL step - the 13-point scatter call (with "
+                         "its riding point-0 planes) of the N-th SDS step after the loss scale has settled, captured once with "
+                         "the first library (`captured_ms`; the synthetic 'real' census has independent zeros, a real step's "
+                         "are clustered by tile, which is what the emit's load balance sees)")
     a = ap.parse_args()
     import raymarching
     from mi3d import _lib as L, field_ops, grid_ops, network, rays as R, sds_step
@@ -103,6 +108,63 @@ def main():
                 times[os.path.basename(p)].append(timeit(call))
         res[census + "_ms"] = times
         del g, ref
+    if a.capture > 0:
+        import bench
+        from mi3d import sd_standin
+        del xs, xs2, ex
+        torch.cuda.empty_cache()
+        L._lib = libs[0]
+        wl = bench.WORKLOADS["c2_dense"]
+        opt = sds_step.make_opt(max_steps=wl["max_steps"])
+        model, optimizer, scaler = sds_step.build_training_state(opt, dev, seed=0, bitfield=wl["bitfield"], init_scale=65536.0)
+        guidance = sd_standin.StableDiffusionStandIn(dev)
+        text_z = guidance.get_text_embeds()
+        ro, rd, ds = R.view_rays(wl["H"], wl["W"], device=dev)
+        torch.manual_seed(1234)
+
+        def sds():
+            sds_step.sds_train_step(model, guidance, text_z, optimizer, scaler, ro, rd, ds, wl["H"], wl["W"], opt,
+                                    sds_backward="reference", t=bench.T_FIXED)
+        good = tries = 0
+        while good < 4 and tries < 60:
+            before = scaler.get_scale()
+            sds()
+            good = good + 1 if scaler.get_scale() >= before else 0
+            tries += 1
+        for _ in range(max(a.capture - 1, 0)):
+            sds()
+        got = {}
+        orig = field_ops.scatter_binned
+
+        def spy(x, x2, offsets, P0_, bound, dplanes, cfg_, step_, n_params, workspace_bytes=None, extra0=None):
+            if offsets.shape[0] == 13:
+                got.update(x=x, x2=x2, offsets=offsets, P0=P0_, bound=bound, dplanes=dplanes.clone(), cfg=cfg_, step=step_,
+                           n_params=n_params, extra0=None if extra0 is None else extra0.clone())
+            return orig(x, x2, offsets, P0_, bound, dplanes, cfg_, step_, n_params, workspace_bytes, extra0)
+        field_ops.scatter_binned = spy
+        sds()
+        field_ops.scatter_binned = orig
+        del model, optimizer, guidance
+        torch.cuda.empty_cache()
+        nzp = (got["dplanes"] != 0).any(-1).float().mean().item()
+        res["captured"] = {"loss_scale": scaler.get_scale(), "steps_before": tries + a.capture - 1, "nonzero_pair_fraction": nzp,
+                           "samples": int(got["x"].shape[0]), "with_point0_planes": got["extra0"] is not None}
+        call = lambda: field_ops.scatter_binned(got["x"], got["x2"], got["offsets"], got["P0"], got["bound"], got["dplanes"],   # noqa: E731
+                                                got["cfg"], got["step"], got["n_params"], extra0=got["extra0"])
+        ref, times = None, {os.path.basename(p): [] for p in paths}
+        for p, lib in zip(paths, libs):
+            L._lib = lib
+            out = call()
+            if ref is None:
+                ref = out
+            else:
+                res[f"captured:{os.path.basename(p)}:max_err_rel_vs_first"] = float((out - ref).abs().max() / ref.abs().max())
+            del out
+        for r in range(a.rounds):
+            for p, lib in zip(paths, libs):
+                L._lib = lib
+                times[os.path.basename(p)].append(timeit(call))
+        res["captured_ms"] = times
     print(json.dumps(res, indent=1))
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
