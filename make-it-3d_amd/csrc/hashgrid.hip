@@ -493,6 +493,13 @@ __device__ __forceinline__ void encode_points(const PointSet &ps, const float (&
     }
 }
 
+#ifndef MI3D_ENCODE_STEAL
+// k_grid_encode_planes: an XCD that has finished its list helps the others with their last segments.  Measured between
+// product-grade builds in one process (tools/gather_ab_libs.py, profiles/gather_ab_libs_r06_steal.json): 22.25 -> 23.35 ms -
+// SLOWER: a helper starts on a table its L2 does not hold, and the tiles it claimed finish after the owner would have
+// finished them.  Not taken (0).
+#define MI3D_ENCODE_STEAL 0
+#endif
 // next unclaimed tile of every plan segment; one slot per launch in flight (zeroed in-stream before the launch)
 constexpr uint32_t kPlanSlots = 64;
 __device__ uint32_t g_encode_next[kPlanSlots * kXcds * kMaxSegs];
@@ -525,12 +532,9 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
 #ifdef MI3D_DEV
     if (threadIdx.x == 0) atomicMin(&mi3d_dbg_encode[xcd * (1 + kMaxSegs)], (unsigned long long)wall_clock64());
 #endif
-    for (uint32_t sg = 0; sg < plan.n_seg[xcd]; ++sg) {
-#ifdef MI3D_DEV
-        if (sg > 0 && threadIdx.x == 0)
-            atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + sg], (unsigned long long)wall_clock64());
-#endif
-        const EncodeSeg seg = plan.seg[xcd][sg];
+    // one segment of XCD x's list: claim its tiles until none is left
+    auto walk = [&](uint32_t x, uint32_t sg, bool own) __attribute__((always_inline)) {
+        const EncodeSeg seg = plan.seg[x][sg];
         const uint32_t l = seg.level;
         const GridLevel L = T.level[l];
         const float2 *lvl = table + L.offset;
@@ -538,14 +542,15 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
         // a coarse level is latency-bound and wants every workgroup the launch has (6 per CU); a fine level thrashes the
         // L1 beyond 3 per CU - the surplus workgroups skip its segments (and, the segments being ordered coarse to fine,
         // retire once the coarse ones are done)
-        if (wg_in_xcd >= seg.wgs) continue;
+        if (wg_in_xcd >= seg.wgs) return;
         const LevelFast F = level_fast(L, ps.mode);
         // Tiles are CLAIMED, not dealt (next[] = the segment's next unclaimed tile; one claim in flight while the wave
         // works on the previous one).  Dealt statically (tile = first + k * stride) the waves of an XCD drifted apart -
         // the CU's oldest-first issue arbitration lets the first-dispatched workgroups finish a segment milliseconds
         // before the last-dispatched ones, they move on, and the XCD's 4 MB L2 then holds two or three levels' tables at
         // once (tools/kbench.py encode_xcds: level 7 still being walked at 28 ms of a 29.6 ms launch).
-        uint32_t *ctr = next ? next + xcd * kMaxSegs + sg : nullptr;
+        uint32_t *ctr = next ? next + x * kMaxSegs + sg : nullptr;
+        if (!ctr && !own) return;
         const uint32_t stride = seg.wgs * kWaves;
         auto claim = [&](uint32_t prev) __attribute__((always_inline)) {
             if (!ctr) return prev + stride;
@@ -564,10 +569,24 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
             else if (F.kind == kHashPow2) encode_points<kHashPow2, PAIR, NT, TRIPLE>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
             else encode_points<kGeneral, PAIR, NT>(ps, base, L, F, lvl, planes, out_half, plane0, n, s);
         }
+    };
+    // The XCD's own list; with MI3D_ENCODE_STEAL (measured: slower, off) then the LAST segment of every other XCD's - the
+    // cost model that cuts the list leaves the XCDs finishing 19.8 to 22.0 ms into a 22 ms launch.  One loop, so that the
+    // point loops are instantiated once.
+    const uint32_t n_own = plan.n_seg[xcd], n_walk = n_own + ((MI3D_ENCODE_STEAL && next) ? kXcds - 1u : 0u);
+    for (uint32_t i = 0; i < n_walk; ++i) {
+        const bool own = i < n_own;
+        const uint32_t x = own ? xcd : (xcd + 1u + (i - n_own)) % kXcds;
+        if (!own && plan.n_seg[x] == 0u) continue;
+#ifdef MI3D_DEV
+        if (i > 0 && i <= n_own && threadIdx.x == 0)
+            atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + i], (unsigned long long)wall_clock64());
+#endif
+        walk(x, own ? i : plan.n_seg[x] - 1u, own);
     }
 #ifdef MI3D_DEV
-    if (threadIdx.x == 0)
-        atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + plan.n_seg[xcd]], (unsigned long long)wall_clock64());
+    if (n_walk == n_own && threadIdx.x == 0)
+        atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + n_own], (unsigned long long)wall_clock64());
 #endif
 }
 
