@@ -2125,92 +2125,107 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 // its loads (16 waves per CU hid that already): a small gain, and the short batch wins.
 #define MI3D_REDUCE_U 4
 #endif
-    constexpr uint32_t U = MI3D_REDUCE_U;  // records in flight per lane
-    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
-        uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
-        cnt = cnt < cap ? cnt : cap;
-        if (row && plan.rec12) {   // binary16 gradient planes: 12-byte pair records
-            const Row12 *src = reinterpret_cast<const Row12 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
-            const bool hashed = T.level[lvl].hashed;
+#ifndef MI3D_REDUCE_PIPE
+// the next batch's record loads issued BEFORE this batch's LDS atomics (two register sets, loop unrolled by two; the ISA
+// shows the older batch waited for with the newer one in flight).  Round 6, product-grade builds in one process
+// (profiles/scatter_ab_libs_r06_reduce_pipe.json; dense / synthetic census / captured real step): off 46.34 / 37.04 / 31.88 ms,
+// on 46.17 / 36.97 / 32.05, on with batches of 2: 46.14 / 36.87 / 31.82, of 8: 46.33 / 37.20 / 32.19 - nothing: the reduce does
+// not wait for its loads, it is bound by the LDS atomics themselves.  Off.
+#define MI3D_REDUCE_PIPE 0
+#endif
+    constexpr uint32_t U = MI3D_REDUCE_U;  // records per lane and batch
+    // A region's records in batches of U per lane.  MI3D_REDUCE_PIPE: the NEXT batch's loads are issued before this batch's
+    // LDS atomics (the loads come back in order, so the wave waits for the older batch only): a wave that loads, waits ~2 us
+    // and then issues its 16 atomic instructions leaves the LDS idle whenever the CU's 16 waves happen to wait together.
+    auto stream = [&](uint32_t cnt, auto load, auto add) __attribute__((always_inline)) {
+        if (cnt == 0u) return;
+        using Rec = decltype(load(0u));
+        if (MI3D_REDUCE_PIPE) {
+            // two register sets, the loop unrolled by two so that neither is ever copied (a copy would wait for its loads);
+            // every load is unconditional from a clamped index (a conditional one is waited for where its block ends)
+            Rec ra[U], rb[U];
+            auto fetch = [&](Rec (&dst)[U], uint32_t at) __attribute__((always_inline)) {
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { const uint32_t i = at + u * kWave + lane; dst[u] = load(i < cnt ? i : cnt - 1u); }
+            };
+            auto consume = [&](const Rec (&src)[U], uint32_t at) __attribute__((always_inline)) {
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u)
+                    if (at + u * kWave + lane < cnt) add(src[u]);
+            };
+            constexpr uint32_t B = kWave * U;
+            fetch(ra, 0u);
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 2u * B) {
+                fetch(rb, i0 + B);
+                consume(ra, i0);
+                fetch(ra, i0 + 2u * B);
+                consume(rb, i0 + B);
+            }
+        } else {
             for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
-                Row12 rec[U];
+                Rec rec[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
                     // (unconditional, from a clamped index: a predicated load makes hipcc wait for it on the spot - the eight
                     // records "in flight" were eight HBM round trips in a row, each behind its own s_waitcnt vmcnt(0), until
                     // round 5 read the ISA; what a lane beyond cnt fetched is never looked at)
                     const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = src[i < cnt ? i : cnt - 1u];
+                    rec[u] = load(i < cnt ? i : cnt - 1u);
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    if (i0 + u * kWave + lane < cnt) {
-                        uint32_t l0, t;
-                        float w, fx, dx, dy;
-                        unpack_row12(rec[u].w0, rec[u].w1, rec[u].w2, l0, t, w, fx, dx, dy);
-                        // (the level's power-of-two scale goes into the weight once - an exact scaling, it commutes with
-                        // every rounding below - instead of into each of the four products)
-                        const float ws = w * scale, a = ws * dx, bb = ws * dy, gx = 1.0f - fx;
-                        atomicAdd(&acc[l0], fixed_point(gx * a));
-                        atomicAdd(&acc[kBinEntries + l0], fixed_point(gx * bb));
-                        if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
-                            // (the flip is masked with the level's size first, as the emit and the 16-byte branch do: a
-                            // table smaller than a bin - log2_hashmap_size < 13 - must not see carry bits beyond it)
-                            const uint32_t l1 = hashed ? (l0 ^ (((1u << t) - 1u) & (T.level[lvl].size - 1u))) & (kBinEntries - 1u)
-                                                       : l0 + 1u;
-                            atomicAdd(&acc[l1], fixed_point(fx * a));
-                            atomicAdd(&acc[kBinEntries + l1], fixed_point(fx * bb));
-                        }
-                    }
-                }
+                for (uint32_t u = 0; u < U; ++u)
+                    if (i0 + u * kWave + lane < cnt) add(rec[u]);
             }
+        }
+    };
+    for (uint32_t r = split * kReduceWaves + wave_in_wg; r < n_waves; r += n_split * kReduceWaves) {
+        uint32_t cnt = counts[plan.level_cnt0[lvl] + (size_t)r * bins + lb];
+        cnt = cnt < cap ? cnt : cap;
+        if (row && plan.rec12) {   // binary16 gradient planes: 12-byte pair records
+            const Row12 *src = reinterpret_cast<const Row12 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
+            const bool hashed = T.level[lvl].hashed;
+            stream(cnt, [&](uint32_t i) { return src[i]; }, [&](const Row12 &rec) {
+                uint32_t l0, t;
+                float w, fx, dx, dy;
+                unpack_row12(rec.w0, rec.w1, rec.w2, l0, t, w, fx, dx, dy);
+                // (the level's power-of-two scale goes into the weight once - an exact scaling, it commutes with
+                // every rounding below - instead of into each of the four products)
+                const float ws = w * scale, a = ws * dx, bb = ws * dy, gx = 1.0f - fx;
+                atomicAdd(&acc[l0], fixed_point(gx * a));
+                atomicAdd(&acc[kBinEntries + l0], fixed_point(gx * bb));
+                if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
+                    // (the flip is masked with the level's size first, as the emit and the 16-byte branch do: a
+                    // table smaller than a bin - log2_hashmap_size < 13 - must not see carry bits beyond it)
+                    const uint32_t l1 = hashed ? (l0 ^ (((1u << t) - 1u) & (T.level[lvl].size - 1u))) & (kBinEntries - 1u)
+                                               : l0 + 1u;
+                    atomicAdd(&acc[l1], fixed_point(fx * a));
+                    atomicAdd(&acc[kBinEntries + l1], fixed_point(fx * bb));
+                }
+            });
         } else if (row) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
             const GridLevel &L = T.level[lvl];
-            for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
-                uint4 rec[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = src[i < cnt ? i : cnt - 1u];   // (unconditional: see the 12-byte branch)
+            stream(cnt, [&](uint32_t i) { return src[i]; }, [&](const uint4 &rec) {
+                const uint32_t e0 = rec.x & ((1u << kRowEntryBits) - 1u), t = rec.x >> kRowEntryBits;
+                const float a = __uint_as_float(rec.y), bb = __uint_as_float(rec.z), fx = __uint_as_float(rec.w);
+                const float gx = 1.0f - fx;
+                const uint32_t l0 = e0 & (kBinEntries - 1);
+                atomicAdd(&acc[l0], fixed_point((gx * a) * scale));
+                atomicAdd(&acc[kBinEntries + l0], fixed_point((gx * bb) * scale));
+                if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
+                    const uint32_t e1 = L.hashed ? (e0 ^ (((1u << t) - 1u) & (L.size - 1u))) : e0 + 1u;
+                    const uint32_t l1 = e1 & (kBinEntries - 1);
+                    atomicAdd(&acc[l1], fixed_point((fx * a) * scale));
+                    atomicAdd(&acc[kBinEntries + l1], fixed_point((fx * bb) * scale));
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    if (i0 + u * kWave + lane < cnt) {
-                        const uint32_t e0 = rec[u].x & ((1u << kRowEntryBits) - 1u), t = rec[u].x >> kRowEntryBits;
-                        const float a = __uint_as_float(rec[u].y), bb = __uint_as_float(rec[u].z),
-                                    fx = __uint_as_float(rec[u].w);
-                        const float gx = 1.0f - fx;
-                        const uint32_t l0 = e0 & (kBinEntries - 1);
-                        atomicAdd(&acc[l0], fixed_point((gx * a) * scale));
-                        atomicAdd(&acc[kBinEntries + l0], fixed_point((gx * bb) * scale));
-                        if (fx != 0.f) {  // a pair: the x + 1 corner sits in the same bin (singles carry fx = 0)
-                            const uint32_t e1 = L.hashed ? (e0 ^ (((1u << t) - 1u) & (L.size - 1u))) : e0 + 1u;
-                            const uint32_t l1 = e1 & (kBinEntries - 1);
-                            atomicAdd(&acc[l1], fixed_point((fx * a) * scale));
-                            atomicAdd(&acc[kBinEntries + l1], fixed_point((fx * bb) * scale));
-                        }
-                    }
-                }
-            }
+            });
         } else {
             const BinRecord *src = reinterpret_cast<const BinRecord *>(arena + plan.level_base[lvl]) + ((size_t)r * bins + lb) * cap;
-            for (uint32_t i0 = 0; i0 < cnt; i0 += kWave * U) {
-                BinRecord rec[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    const uint32_t i = i0 + u * kWave + lane;
-                    rec[u] = src[i < cnt ? i : cnt - 1u];   // (unconditional: see the 12-byte branch)
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    if (i0 + u * kWave + lane < cnt) {
-                        const uint32_t local = rec[u].entry & (kBinEntries - 1);
-                        atomicAdd(&acc[local], fixed_point(rec[u].g0 * scale));
-                        atomicAdd(&acc[kBinEntries + local], fixed_point(rec[u].g1 * scale));
-                    }
-                }
-            }
+            stream(cnt, [&](uint32_t i) { return src[i]; }, [&](const BinRecord &rec) {
+                const uint32_t local = rec.entry & (kBinEntries - 1);
+                atomicAdd(&acc[local], fixed_point(rec.g0 * scale));
+                atomicAdd(&acc[kBinEntries + local], fixed_point(rec.g1 * scale));
+            });
         }
         any |= cnt != 0;
     }
