@@ -920,7 +920,7 @@ def main():
             roof("grid gradient scatter: one mi3d_grid_scatter_binned_plus call = (k_bin_emit + k_bin_reduce) x slices "
                  "(records through HBM, no global atomics)", "scatter", SCATTER_BYTES_PER_EVAL, "hbm", HBM_PEAK_GBPS,
                  "GB/s", "a 'launch' here is one scatter call (kernel-trace: sum the k_bin_emit and k_bin_reduce rows of a "
-                 "step: profiles/kernel_stats_r05_bench_steps.csv, collected on THIS command's own timed steps with "
+                 "step: profiles/kernel_stats_r06_bench_steps.csv, collected on THIS command's own timed steps with "
                  "--profile-run); algorithmic bytes = 2048 B per evaluation read-modify-write of the table, counted ONLY for "
                  "the (evaluation, level) gradient pairs that are not exactly zero (grad_nonzero_pair_fraction: binary16 "
                  "gradients underflow, and adding a zero is what the reference's atomics would do); dense-gradient figures: "

@@ -926,7 +926,10 @@ int launch_scatter(const PointSet &ps, uint32_t n, const int32_t *count, const f
 // on both: 13-point scatter + deferred point-0 pair, one box, tools/kbench.py --what scatter_ab: dense gradients 62.25 ->
 // 61.57 ms, a real step's zero census 40.87 -> 39.77 ms, whole steps -1.9 ms (tools/step_ab.py, anchored A/B); 5.8 steps
 // (level 6 as records too): real 39.1, dense 66.2 - not taken (profiles/kbench_r04_scatter_ab.json).
-inline float merge_steps() { return (float)MI3D_TUNE(MI3D_T_MERGE_STEPS_X10, 42) / 10.5f; }
+#ifndef MI3D_MERGE_STEPS_X10_DEFAULT
+#define MI3D_MERGE_STEPS_X10_DEFAULT 42
+#endif
+inline float merge_steps() { return (float)MI3D_TUNE(MI3D_T_MERGE_STEPS_X10, MI3D_MERGE_STEPS_X10_DEFAULT) / 10.5f; }
 
 // levels whose cells are longer than one marching step `step01` (in [0,1] units) try to merge neighbours
 uint32_t default_merge_levels(const GridTable &T, float step01) {

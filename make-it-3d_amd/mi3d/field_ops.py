@@ -25,8 +25,7 @@ from . import grid_ops
 from . import mlp_ops
 
 # Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples, so
-# the samples are processed in slices that fit (mi3d_grid_scatter_binned halves the slice until its plan fits the
-# workspace it is handed).  It is a plain torch allocation made per call: the caching allocator hands the same block
+# the samples are processed in the fewest equal slices that fit (mi3d_grid_scatter_binned: csrc/hashgrid.hip slice_for).  It is a plain torch allocation made per call: the caching allocator hands the same block
 # back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
 WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56")) * (1 << 30))
 
