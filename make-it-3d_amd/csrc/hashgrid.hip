@@ -2128,6 +2128,13 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 // its loads (16 waves per CU hid that already): a small gain, and the short batch wins.
 #define MI3D_REDUCE_U 4
 #endif
+#ifndef MI3D_REDUCE_BASE_SPLIT
+// reduce workgroups per average bin for slices of 30 M evaluations and more (plan_reduce_splits).  Round 6, product-grade builds
+// in one process (profiles/scatter_ab_libs_r06_reduce_split.json; dense / synthetic census / captured real step, ms): 3: 44.78 /
+// 38.24 / 32.21, 4: 44.85 / 38.25 / 32.28, 6: 44.93 / 38.39 / 32.27, 8: 44.96 / 38.47 / 32.45 - flat: the reduce's tail is not where
+// its time goes
+#define MI3D_REDUCE_BASE_SPLIT 4
+#endif
 #ifndef MI3D_REDUCE_PIPE
 // the next batch's record loads issued BEFORE this batch's LDS atomics (two register sets, loop unrolled by two; the ISA
 // shows the older batch waited for with the newer one in flight).  Round 6, product-grade builds in one process
@@ -2593,7 +2600,7 @@ int mi3d_grid_scatter_binned_plus(const float *x, const float *x2, uint32_t n, c
                                    plan, merge_levels, fine_mask, fine_waves, coarse_mask, coarse_waves, emit_order,
                                    reinterpret_cast<BinRecord *>(arena), counts, level_max, grad_params);
         }
-        const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? 4u : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
+        const uint32_t n_split = (uint64_t)(s1 - s0) * P >= 30000000ull ? (uint32_t)MI3D_REDUCE_BASE_SPLIT : ((uint64_t)(s1 - s0) * P >= 8000000ull ? 2u : 1u);
         plan_reduce_splits(plan, T, n_split, merge_levels);
         hipLaunchKernelGGL(k_bin_reduce, dim3(plan.n_reduce_wgs), dim3(kWave * kReduceWaves), lds_reduce, st, arena,
                            counts, level_max, T, plan, grad_params);
@@ -2647,7 +2654,7 @@ int mi3d_grid_scatter_plan(uint32_t n, uint32_t P, float bound, float step, uint
     BinPlan p;
     const uint64_t n_slice = slice_for(T, n, P, step01, merge_levels, false, workspace_bytes, p);  // as mi3d_grid_scatter_binned
     const uint64_t evals = n_slice * P;
-    plan_reduce_splits(p, T, evals >= 30000000ull ? 4u : (evals >= 8000000ull ? 2u : 1u), merge_levels);
+    plan_reduce_splits(p, T, evals >= 30000000ull ? (uint32_t)MI3D_REDUCE_BASE_SPLIT : (evals >= 8000000ull ? 2u : 1u), merge_levels);
     out[0] = n_slice; out[1] = bin_workspace_bytes(p); out[2] = merge_levels; out[3] = p.n_reduce_wgs;
     out[4] = p.total_bytes; out[5] = p.total_counts;
     for (uint32_t l = 0; l < n_levels; ++l) {
