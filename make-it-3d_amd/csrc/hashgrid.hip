@@ -628,15 +628,30 @@ __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(Poi
     }
 }
 
+#ifndef MI3D_ENCODE_COST_FIT
+#define MI3D_ENCODE_COST_FIT 6   // which round's fit of the per-level cost table make_encode_plan balances the XCDs with
+#endif
 // Relative cost of one tile of a level, as a function of x = (marching step) x (level scale) = how many cells of the
 // level two consecutive samples of a ray are apart: the measured per-level times above, tabulated against x (C2: step
 // 2 sqrt(3) / 1024 in a box of side 2) and interpolated, so other step sizes and grid configurations balance too.
 inline double encode_level_cost(double x, bool dense_fast) {
     // round 3, after the short index routes (profiles/kbench_r03_encode_fast.json): ms per level at C2 with 6 workgroups
     // per CU up to x = 0.26 and 3 beyond.  A dense level on the short route is instruction-bound and flat.
-    if (dense_fast) return 0.44;
     static const double xs[] = {0.0, 0.136, 0.19, 0.26, 0.36, 0.50, 0.69, 0.95, 1.30, 1.80, 2.50, 3.50};
+#if MI3D_ENCODE_COST_FIT == 3
+    if (dense_fast) return 0.44;
     static const double cs[] = {0.74, 0.76, 0.84, 0.94, 1.10, 1.50, 1.98, 2.55, 2.87, 3.03, 3.06, 3.08};
+#else
+    // round 6: re-fitted IN SITU - what a tile of each level costs its XCD while the other seven walk theirs, from the
+    // per-XCD, per-segment timestamps of the whole gather (tools/encode_xcd_timeline.py, profiles/encode_xcd_timeline_r06*.json;
+    // tile-weighted ms per 1000 tiles of one XCD x 170 / 8, segments of 20 000 tiles and more, two plans).  Round 3's table came from per-level launches of the whole chip; under it the
+    // XCDs finished 20.3 to 21.9 ms into the launch; under this one 20.6 to 22.2 on another box (what an XCD's tile costs moves
+    // by ~5 % with the box and with what the other XCDs are doing): 22.25-22.98 ms against 22.37-23.0 for round 3's table between
+    // product builds in one process (profiles/gather_ab_libs_r06_cost_fit.json) - equal within the run-to-run spread.  The
+    // balance of the XCDs is worth <= 0.9 ms (mean end 21.0 against the last one's 21.9) and a static table cannot have it.
+    if (dense_fast) return 0.383;
+    static const double cs[] = {0.67, 0.685, 0.80, 0.853, 0.982, 1.416, 1.819, 2.246, 2.656, 2.72, 2.895, 2.78};
+#endif
     constexpr int N = sizeof(xs) / sizeof(xs[0]);
     if (x <= xs[0]) return cs[0];
     for (int i = 1; i < N; ++i)
