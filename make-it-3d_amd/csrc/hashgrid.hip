@@ -209,6 +209,7 @@ struct EncodeSeg { uint32_t level, tile0, tile1, wgs; };  // wgs: workgroups of 
 struct EncodePlan {
     uint32_t n_seg[kXcds];
     EncodeSeg seg[kXcds][kMaxSegs];
+    uint32_t shared;   // 1: every XCD walks the SAME list - whole levels, in order - and all claim from one counter per level
 };
 
 template <bool PAIR>
@@ -573,16 +574,29 @@ __global__ __launch_bounds__(kWave *kWaves) void k_grid_encode_planes(PointSet p
     // The XCD's own list; with MI3D_ENCODE_STEAL (measured: slower, off) then the LAST segment of every other XCD's - the
     // cost model that cuts the list leaves the XCDs finishing 19.8 to 22.0 ms into a 22 ms launch.  One loop, so that the
     // point loops are instantiated once.
-    const uint32_t n_own = plan.n_seg[xcd], n_walk = n_own + ((MI3D_ENCODE_STEAL && next) ? kXcds - 1u : 0u);
+    // (plan.shared: all eight XCDs walk the levels TOGETHER - segment sg of every XCD is its eighth of level sg's tiles, and an
+    //  XCD that is through with its eighth claims from the others' before anybody moves on to the next level)
+    const uint32_t n_own = plan.n_seg[xcd];
+    const uint32_t n_walk = plan.shared ? n_own * (next ? kXcds : 1u) : n_own + ((MI3D_ENCODE_STEAL && next) ? kXcds - 1u : 0u);
     for (uint32_t i = 0; i < n_walk; ++i) {
-        const bool own = i < n_own;
-        const uint32_t x = own ? xcd : (xcd + 1u + (i - n_own)) % kXcds;
-        if (!own && plan.n_seg[x] == 0u) continue;
+        bool own;
+        uint32_t x, sg;
+        if (plan.shared) {
+            const uint32_t k = next ? i % kXcds : 0u;
+            sg = next ? i / kXcds : i;
+            own = k == 0u;
+            x = (xcd + k) % kXcds;
+        } else {
+            own = i < n_own;
+            x = own ? xcd : (xcd + 1u + (i - n_own)) % kXcds;
+            if (!own && plan.n_seg[x] == 0u) continue;
+            sg = own ? i : plan.n_seg[x] - 1u;
+        }
 #ifdef MI3D_DEV
-        if (i > 0 && i <= n_own && threadIdx.x == 0)
+        if (!plan.shared && i > 0 && i <= n_own && threadIdx.x == 0)
             atomicMax(&mi3d_dbg_encode[xcd * (1 + kMaxSegs) + i], (unsigned long long)wall_clock64());
 #endif
-        walk(x, own ? i : plan.n_seg[x] - 1u, own);
+        walk(x, sg, own);
     }
 #ifdef MI3D_DEV
     if (n_walk == n_own && threadIdx.x == 0)
@@ -628,6 +642,15 @@ __global__ __launch_bounds__(kWave *kLdsWaves) void k_grid_encode_planes_lds(Poi
     }
 }
 
+#ifndef MI3D_ENCODE_SHARED_LEVELS
+// 1: all eight XCDs walk the levels TOGETHER (each its eighth of a level's tiles first, then the others' eighths) instead of
+// one contiguous stretch of the (level, tile) list per XCD cut by a cost model.  Round 6, product builds in one process
+// (tools/gather_ab_libs.py; planes bit-identical): per-XCD stretches 21.89-22.73 ms (mean 22.27), together 22.47-22.53
+// (profiles/gather_ab_libs_r06_shared_levels.json) - the perfect balance buys nothing once every level change is a change for
+// the whole chip; with ONE claim counter per level for all XCDs 32.5 ms (profiles/gather_ab_libs_r06_shared_one_counter.json:
+// ~75 M claims/s is what one address takes).  Not taken (0).
+#define MI3D_ENCODE_SHARED_LEVELS 0
+#endif
 #ifndef MI3D_ENCODE_COST_FIT
 #define MI3D_ENCODE_COST_FIT 6   // which round's fit of the per-level cost table make_encode_plan balances the XCDs with
 #endif
@@ -676,6 +699,20 @@ inline EncodePlan make_encode_plan(const GridTable &T, uint32_t n_tiles, float s
         if (l < first_level) cost[l] = 0.0;  // served from LDS by k_grid_encode_planes_lds
         total += cost[l];
     }
+#if MI3D_ENCODE_SHARED_LEVELS
+    // all eight XCDs walk level l together, each its eighth of the tiles first (its own claim counter: ONE counter for the
+    // whole chip was measured at 32.5 ms against 22.2 - ~75 M claims/s is what one address takes), then the others' eighths
+    // (the table is in every L2 by then): no cost model, no XCD finishing early
+    {
+        plan.shared = 1u;
+        for (uint32_t x = 0; x < kXcds; ++x)
+            for (uint32_t l = 0; l < T.n_levels; ++l)
+                if (cost[l] > 0.0 && plan.n_seg[x] < (uint32_t)kMaxSegs)
+                    plan.seg[x][plan.n_seg[x]++] = EncodeSeg{l, (uint32_t)((uint64_t)n_tiles * x / kXcds), (uint32_t)((uint64_t)n_tiles * (x + 1) / kXcds), encode_level_wgs_per_cu((double)step01 * (double)T.level[l].scale,
+                                                                                                  wgs_coarse_per_xcd, wgs_fine_per_xcd)};
+        return plan;
+    }
+#endif
     const double share = total / kXcds;
     uint32_t x = 0;
     double filled = 0.0;  // cost already given to XCD x
