@@ -27,7 +27,7 @@ from . import mlp_ops
 # Upper bound of the scatter's record arena, bytes.  The arena holds every corner contribution of a slice of samples, so
 # the samples are processed in the fewest equal slices that fit (mi3d_grid_scatter_binned: csrc/hashgrid.hip slice_for).  It is a plain torch allocation made per call: the caching allocator hands the same block
 # back every step, it is stream-safe, and torch.cuda.empty_cache() releases it.
-WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56")) * (1 << 30))
+WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "33")) * (1 << 30))
 
 
 # ---- where the record arena LIES matters (round 6, DESIGN.md 3.2: "the placement of the arena") -------------------------
@@ -43,7 +43,9 @@ WORKSPACE_CAP_BYTES = int(float(os.environ.get("MI3D_SCATTER_WORKSPACE_GB", "56"
 # PLACEMENT_TRIALS candidate blocks are allocated side by side, the caller's own scatter is timed on each with synthetic
 # dense gradients, the fastest is kept and the others are returned to the driver (~1 s, once).
 PLACED_MIN_BYTES = 8 << 30
-PLACEMENT_TRIALS = int(os.environ.get("MI3D_SCATTER_PLACEMENT_TRIALS", "4"))   # 1 = take the first block as it comes
+# candidate blocks: 1 = take the first block as it comes; unset = 7 for an arena below 40 GiB, 4 above (of six runs at 20-33 GiB
+# one was offered no fast block among four candidates, none of the runs at 56 GiB: profiles/bench_r06_arena_cap_claimed_tiles.json)
+PLACEMENT_TRIALS = int(os.environ.get("MI3D_SCATTER_PLACEMENT_TRIALS", "0"))
 _ARENA_LOCK = threading.RLock()   # (autograd runs backward passes on worker threads, one per device)
 _ARENAS = {}          # device index -> the persistent arena (uint8 tensor)
 _ARENA_LAST_USE = {}  # device index -> event behind the last scatter that used it (torch's allocator no longer orders them)
@@ -93,10 +95,11 @@ def scatter_workspace(device, needed, cap=None, trial=None):
         if held is not None:                       # a larger one is needed: the old one goes first
             del _ARENAS[device.index], held
         n_try = 1
-        if trial is not None and PLACEMENT_TRIALS > 1:
+        trials = PLACEMENT_TRIALS if PLACEMENT_TRIALS > 0 else (7 if want < (40 << 30) else 4)
+        if trial is not None and trials > 1:
             torch.cuda.empty_cache()               # (cached blocks would only shrink the room for candidates)
             free, _ = torch.cuda.mem_get_info(device)
-            n_try = max(1, min(PLACEMENT_TRIALS, int(0.9 * free) // want))
+            n_try = max(1, min(trials, int(0.9 * free) // want))
         # candidates SPREAD over the free memory (a spacer in front of each): blocks allocated back to back sit next to
         # each other, and whole stretches of the device memory are slow for this write stream - at 32 GiB the first three of
         # six back-to-back candidates timed 61-62 ms, the next three 52-54 (profiles/bench_r06_arena_cap_curve.json)
@@ -215,13 +218,29 @@ def _forward_encode_mlp(params, ws, x, x2, offs, offs_p, P0, bound, cfg, half_mo
     return feats, h, dims
 
 
-def _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active):
+def _last_pass_through_graph():
+    """True when the backward pass now running frees the graph behind it (no retain_graph): whatever this node saved for
+    backward is dead once this call returns.  False whenever that cannot be established."""
+    try:
+        return not bool(torch._C._autograd._get_current_graph_task_keep_graph())
+    except Exception:  # noqa: BLE001 - the private probe is gone, or no graph task is running
+        return False
+
+
+def _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active, in_place=False):
     """(dplanes [L][P_active*n][2], [dW1, db1, dW2, db2, dW3, db3]) from dh [P_active*n, 4]: the MLP backward over the
-    first P_active points of the stencil only."""
+    first P_active points of the stencil only.  `in_place`: the gradient planes are written OVER the feature planes (the
+    caller knows them dead after this pass) - a wave reads a tile's 32 rows of every plane into registers before it stores
+    the same rows' gradients and no other wave touches those rows, so the kernel is indifferent; 9.05 GB less at the step's
+    memory peak.  Only for whole passes over whole tiles (rows == plane rows, a multiple of 32: a partial tile's idle lanes
+    re-read the last row, which another wave may have overwritten by then)."""
     n = x.shape[0]
     rows, plane_rows = P_active * n, feats.shape[1]
-    # binary16 gradient planes under autocast: what the reference's binary16 dgrad GEMM hands the encoder's backward
-    dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=feats.dtype, device=x.device)
+    if in_place and rows == plane_rows and rows % 32 == 0 and feats.is_contiguous():
+        dplanes = feats
+    else:
+        # binary16 gradient planes under autocast: what the reference's binary16 dgrad GEMM hands the encoder's backward
+        dplanes = torch.empty(cfg["n_levels"], rows, 2, dtype=feats.dtype, device=x.device)
     grads = [None if t is None else torch.zeros_like(t) for t in ws]
     grid_ops._timed("mlp_bwd", lambda: L.call(
         "mi3d_mlp_backward", L.ptr(feats), plane_rows, int(feats.dtype == torch.float16), L.ptr(dh), rows,
@@ -554,7 +573,12 @@ class _Field(Function):
         with L.on(x):
             dh = _head_backward(h, x, x2 if has_x2 else None, offs, bound, blob_density, blob_radius, epsilon, grads,
                                 P_active)
-            dplanes, wg = _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active)
+            # the last pass through this forward (no retain_graph) over the whole stencil: the gradient planes take the
+            # feature planes' place (grid_ops.INPLACE_GRAD_PLANES) - both were live at the step's memory peak
+            dplanes, wg = _backward_mlp(dh, feats, ws, dims, x, cfg, half_mode, P_active,
+                                        in_place=grid_ops.INPLACE_GRAD_PLANES and P_active == offs.shape[0]
+                                        and _last_pass_through_graph())
+            del dh
             if _may_defer(param, offs.shape[0], P_active):
                 # nerf/sd.py:171's pass: nothing is scattered now - the planes wait for the pass that follows (or for
                 # the first reader of encoder.params.grad)

@@ -64,6 +64,11 @@ def _timed(kind, launch, evals):
     PROFILE.setdefault(kind + "_evals", []).append(evals)
 
 
+# The fused field's LAST backward pass through a forward (no retain_graph) over the whole stencil writes its feature-gradient
+# planes over the feature planes it saved (field_ops._backward_mlp): the two 9.05 GB sets of planes were both live at the C2
+# step's memory peak.  False = always a buffer of their own.
+INPLACE_GRAD_PLANES = True
+
 # The reference's SDS step back-propagates TWICE through one forward (nerf/sd.py:171 `latents.backward(gradient=grad,
 # retain_graph=True)`, then nerf/utils.py:983 `scaler.scale(loss).backward()`).  The first pass reaches the field through
 # the image only: sigma / albedo of stencil point 0.  With DEFER_POINT0 the fused field node does NOT scatter that pass's
