@@ -2180,6 +2180,13 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
 // its loads (16 waves per CU hid that already): a small gain, and the short batch wins.
 #define MI3D_REDUCE_U 4
 #endif
+#ifndef MI3D_TIMING_REDUCE_NO_FLUSH
+// TIMING ONLY: a reduce workgroup ends with up to 16 384 float atomics into the table (49 M per slice, at the chip's 21 G/s that
+// would be 2.3 ms).  Without them (round 6, product builds in one process, three slices: profiles/scatter_ab_libs_r06_reduce_flush_33GiB.json)
+// dense 47.51 -> 47.21 ms, captured real step 32.70 -> 32.65: they cost nothing - the wave ends behind them, the next workgroup's
+// LDS atomics run meanwhile.  (2 / 3 workgroups per bin instead of 4, same file: nothing either.)
+#define MI3D_TIMING_REDUCE_NO_FLUSH 0
+#endif
 #ifndef MI3D_REDUCE_BASE_SPLIT
 // reduce workgroups per average bin for slices of 30 M evaluations and more (plan_reduce_splits).  Round 6, product-grade builds
 // in one process (profiles/scatter_ab_libs_r06_reduce_split.json; dense / synthetic census / captured real step, ms): 3: 44.78 /
@@ -2295,10 +2302,14 @@ __global__ __launch_bounds__(kWave *kReduceWaves) void k_bin_reduce(const char *
     const uint32_t e0 = lb * kBinEntries;
     const uint32_t live = T.level[lvl].size - e0 < kBinEntries ? T.level[lvl].size - e0 : kBinEntries;  // last bin of a level
     float *dst = grad_table + ((size_t)T.level[lvl].offset + e0) * 2;
+#if MI3D_TIMING_REDUCE_NO_FLUSH   // TIMING ONLY (the gradient is lost): what the float atomics that end a reduce workgroup cost
+    if (live == 0xFFFFFFFFu) dst[threadIdx.x] = (float)((double)(long long)acc[threadIdx.x] * unscale);
+#else
     for (uint32_t i = threadIdx.x; i < live * 2; i += blockDim.x) {
         const long long a = (long long)acc[(i & 1u) * kBinEntries + (i >> 1)];
         if (a != 0) unsafeAtomicAdd(dst + i, (float)((double)a * unscale));
     }
+#endif
 }
 
 // grad[i] += sum over the n_rep private copies
