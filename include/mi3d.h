@@ -230,8 +230,8 @@ int mi3d_grid_scatter_points(const float *x, const float *x2, uint32_t n, const 
  * atomicAdd would have put it on (and nowhere else).
  * `dout_planes` is level-major [n_levels][P*n][2], rows point-major (what mi3d_mlp_backward writes with
  * dx_plane_rows = P*n); dout_half != 0: binary16 pairs (see mi3d_grid_encode_points_planes).
- * `workspace` is caller-provided device scratch (never allocated here); samples are processed in slices that fit
- * it; with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
+ * `workspace` is caller-provided device scratch (never allocated here); samples are processed in the FEWEST equal
+ * slices whose record arena fits it (ceil(n / k), k = 1, 2, 3 ...; the emit's tile-claim counters live in it too); with workspace == NULL or too small for even 64 samples the atomic kernels of mi3d_grid_scatter_points run
  * instead.  mi3d_grid_scatter_binned_workspace() returns the size that lets n samples go in ONE slice. */
 size_t mi3d_grid_scatter_binned_workspace(uint32_t n, uint32_t P, float bound, float step, uint32_t n_levels,
                                           uint32_t base_resolution, float per_level_scale, uint32_t log2_hashmap_size);
